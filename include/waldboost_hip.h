@@ -1,0 +1,173 @@
+/*
+ * waldboost_hip.h -- C ABI of the MI355X (gfx950) waldboost detection hot path.
+ *
+ * The reference (RomanJuranek/waldboost) is pure Python and has no FFI/plugin
+ * seam: the hot path sits behind plain Python calls.  This ABI is the seam the
+ * build puts *beneath* that Python surface; each entry point names the
+ * reference code it replaces.  All pointers marked "dev" are device pointers
+ * supplied by the caller (e.g. torch ``data_ptr()``); no entry point allocates
+ * result memory, synchronises the device, or throws.  Every function returns
+ * WB_OK (0) or a negative error code; wb_last_error() gives the thread-local
+ * message.  ``stream`` is a hipStream_t passed as void* (NULL = default stream).
+ *
+ *   reference waldboost/channels.py:93-101 (_image_octaves) + :55-64 (avg_pool_2)
+ *        -> wb_octaves_launch
+ *   reference waldboost/channels.py:111-146 (channel_pyramid: resize :132,
+ *        grad_hist :40-52, gradients :16-21, avg_pool_2 :55-64, smooth :78-90)
+ *        -> wb_channels_launch
+ *   reference waldboost/model.py:62-67,272-283 (Model ctor/append) +
+ *        waldboost/training.py:24-31 (DTree.__init__)
+ *        -> wb_model_create / wb_model_destroy / wb_model_info
+ *   reference waldboost/model.py:216-259 (Model.predict_on_image) +
+ *        waldboost/training.py:84-96 (DTree.predict_on_image)
+ *        -> wb_cascade_launch
+ *   reference waldboost/training.py:84-96 called on explicit (rs, cs) lists
+ *        -> wb_tree_eval_launch
+ *   reference waldboost/model.py:136-147 (Model.get_boxes)
+ *        -> wb_boxes_launch
+ */
+#ifndef WALDBOOST_HIP_H
+#define WALDBOOST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WB_ABI_VERSION 1
+
+#define WB_OK 0
+#define WB_ERR_INVALID (-1)     /* bad argument / malformed model */
+#define WB_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define WB_ERR_UNSUPPORTED (-3) /* valid input this build has no kernel for */
+
+#define WB_DTYPE_U8 0
+#define WB_DTYPE_F32 1
+
+#define WB_LAYOUT_PLANAR 0 /* [C][u][vp], vp = v rounded up to 4 floats (kernel-internal) */
+#define WB_LAYOUT_HWC 1    /* [u][v][C], the layout channel_pyramid hands to callers     */
+
+#define WB_MAX_OCTAVES 24
+
+/* One pyramid level (reference channels.py:127-146).  Built on the host: the level
+ * plan is Python-float arithmetic in the reference and stays there. */
+typedef struct WbLevel {
+    int32_t oct;      /* source octave index                                        */
+    int32_t src_h;    /* octave base size                                           */
+    int32_t src_w;
+    int32_t nh;       /* resized size (multiple of shrink)                          */
+    int32_t nw;
+    int32_t u;        /* channel image size = nh/shrink, nw/shrink                  */
+    int32_t v;
+    int32_t vp;       /* planar row pitch in floats (v rounded up to 4)             */
+    int64_t src_off;  /* element offset of the octave in the per-image octave buffer;
+                         octave 0 lives in the image buffer itself (src_off unused) */
+    int64_t chn_off;  /* float offset of this level in the per-image channel buffer */
+    double sy;        /* zoom step src_h/nh (fp64 division, as scipy zoom does)     */
+    double sx;        /* src_w/nw                                                   */
+} WbLevel;            /* 64 bytes */
+
+/* One workgroup's tile: level index + tile coordinates (in tiles). */
+typedef struct WbTile {
+    int32_t level;
+    uint16_t ty;
+    uint16_t tx;
+} WbTile; /* 8 bytes */
+
+/* One detection: window (r, c) of pyramid level `level` of image `image`
+ * survived every stage with accumulated response `score` (model.py:255-259). */
+typedef struct WbDet {
+    int32_t image;
+    int32_t level;
+    uint16_t r;
+    uint16_t c;
+    float score;
+} WbDet; /* 16 bytes */
+
+typedef struct WbModel WbModel; /* opaque */
+
+typedef struct WbModelInfo {
+    int32_t n_stages;
+    int32_t depth;      /* depth of the canonical complete trees the kernels walk  */
+    int32_t m, n, C;    /* window shape (rows, cols, channels)                     */
+    int32_t tile_rows;  /* cascade tile: tile_rows x 64 windows per workgroup      */
+    int32_t tile_cols;
+    int32_t lds_bytes;  /* dynamic LDS per workgroup of the cascade kernel         */
+} WbModelInfo;
+
+int wb_abi_version(void);
+const char *wb_last_error(void);
+
+/* Tile sizes of the channel kernel for a given shrink (outputs per workgroup). */
+int wb_channels_tile(int shrink, int *tile_u, int *tile_v);
+
+/* Octave pyramid of the raw image + per-octave min/max (the clip range of the resize).
+ *   img      dev  [batch][H][W] of dtype, image b at img + b*img_stride elements
+ *   oct      dev  per-image octave buffer for octaves 1..n_oct-1 (octave k at
+ *                 oct + b*oct_stride + oct_off[k]); oct_off is a HOST array of n_oct
+ *                 element offsets (oct_off[0] ignored)
+ *   minmax   dev  uint32 [batch][n_oct][2] order-preserving keys of (min, max)
+ * uint8 pooling wraps mod 256 before the divide, as the reference does under NumPy
+ * (SURVEY S2); float32 pooling is ((a+b)+c)+d then /4. */
+int wb_octaves_launch(void *stream, const void *img, int dtype, int batch, int H, int W,
+                      int64_t img_stride, void *oct, int64_t oct_stride, const int64_t *oct_off,
+                      int n_oct, uint32_t *minmax);
+
+/* All levels of all images: bilinear resize (fp64) -> Sobel gradients -> 4 oriented
+ * channels (fp64 projection) -> shrink -> 3x3 smooth, fused per tile.
+ *   levels   dev  WbLevel[n_levels];  tiles dev WbTile[n_tiles] (tile = wb_channels_tile)
+ *   cs_sn    HOST double[8]: cos(theta_k), k=0..3 then sin(theta_k) (channels.py:43-46)
+ *   chn      dev  float, image b at chn + b*chn_stride, level l at + levels[l].chn_off
+ *   layout   WB_LAYOUT_PLANAR or WB_LAYOUT_HWC (HWC uses pitch v, planar pitch vp) */
+int wb_channels_launch(void *stream, const void *img, int64_t img_stride, const void *oct,
+                       int64_t oct_stride, int dtype, int batch, const WbLevel *levels, int n_levels,
+                       const WbTile *tiles, int n_tiles, const uint32_t *minmax, int n_oct,
+                       int shrink, int smooth, const double *cs_sn, float *chn, int64_t chn_stride,
+                       int layout);
+
+/* Build the device-side cascade from the reference's tree arrays (all HOST pointers).
+ *   node_off  int32[n_stages+1]  first node of each stage's tree in the flat arrays
+ *   feature   uint8[n_nodes][3]  (row, col, channel) inside the window
+ *   threshold float[n_nodes], left/right int8[n_nodes] (-1 on leaves), prediction float[n_nodes]
+ *   theta     float[n_stages]    rejection thresholds, -inf = stage never rejects
+ * Trees must have parent index < child index (the order the reference walks them in,
+ * training.py:88).  Returns WB_ERR_UNSUPPORTED for trees deeper than 3. */
+int wb_model_create(int n_stages, const int32_t *node_off, const uint8_t *feature,
+                    const float *threshold, const int8_t *left, const int8_t *right,
+                    const float *prediction, const float *theta, int m, int n, int C,
+                    WbModel **out);
+int wb_model_destroy(WbModel *model);
+int wb_model_info(const WbModel *model, WbModelInfo *info);
+
+/* Dense sliding-window cascade over all levels of all images.
+ *   chn/layout    as written by wb_channels_launch (or caller-provided HWC arrays)
+ *   tiles         dev WbTile[n_tiles]: tiles of tile_rows x tile_cols WINDOWS over the
+ *                 (u-m) x (v-n) window grid of each level
+ *   det           dev WbDet[capacity]; det_count dev uint32: number of survivors (may
+ *                 exceed capacity: records beyond capacity are dropped, count is exact)
+ *   alive         dev uint32 [batch][n_levels][n_stages]: windows entering each stage
+ * det_count and alive are ACCUMULATED into: the caller zeroes them. Record order is
+ * unspecified; sort by (image, level, r, c) to obtain the reference order. */
+int wb_cascade_launch(void *stream, const WbModel *model, const float *chn, int64_t chn_stride,
+                      int layout, int batch, const WbLevel *levels, int n_levels,
+                      const WbTile *tiles, int n_tiles, WbDet *det, uint32_t *det_count,
+                      uint32_t capacity, uint32_t *alive);
+
+/* One tree evaluated at explicit window origins (rs[i], cs[i]) of an HWC channel image
+ * X[u][v][C]; out[i] = prediction of the leaf reached (training.py:84-96). Tree arrays
+ * and rs/cs/out are dev pointers. */
+int wb_tree_eval_launch(void *stream, const float *X, int u, int v, int C, const int32_t *rs,
+                        const int32_t *cs, int64_t n_pos, const uint8_t *feature,
+                        const float *threshold, const int8_t *left, const int8_t *right,
+                        const float *prediction, int n_nodes, float *out);
+
+/* XYXY float32 boxes of detections: [c, r, c+n, r+m] * (1/scale[level]) (model.py:136-147).
+ *   inv_scale  dev float[n_levels] = float32(1.0/scale) computed on the host in fp64 */
+int wb_boxes_launch(void *stream, const WbDet *det, int64_t n_det, const float *inv_scale,
+                    int m, int n, float *boxes /* [n_det][4] */, float *scores /* [n_det] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WALDBOOST_HIP_H */

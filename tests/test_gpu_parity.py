@@ -1,0 +1,226 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the
+C ABI via the reference-shaped Python surface, against the golden fixtures generated from the
+reference and against the CPU oracle on the same seeded inputs.
+
+Bar: channel arrays, window indices and per-stage alive counts bit-exact; scores bit-exact
+(the north-star tolerance is 1e-5, the kernels accumulate in the reference's order so the test
+asks for equality); boxes bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import waldboost_amd as wb
+from oracle import wb_oracle as orc
+from waldboost_amd.synth import synth_image, random_tree_arrays
+from util import GOLDEN, golden_meta, oracle_detect, oracle_model, small_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_same_detections(res, ref):
+    assert np.array_equal(res["alive"], ref["alive"])
+    assert np.array_equal(res["level"], ref["level"])
+    assert np.array_equal(res["r"], ref["r"]) and np.array_equal(res["c"], ref["c"])
+    assert np.array_equal(bits(res["scores"]), bits(ref["scores"]))
+    assert np.array_equal(bits(res["boxes"]), bits(ref["boxes"]))
+
+
+def random_model(seed, T, depth, shape=(12, 12, 4), opts=None, survive=0.85, mixed=False):
+    rng = np.random.default_rng(seed)
+    opts = opts or dict(wb.default_channel_opts)
+    M = wb.Model(shape, opts)
+    acc = 0.0
+    for t in range(T):
+        d = depth
+        unb = False
+        if mixed:
+            d = int(rng.integers(1, 4))
+            unb = d == 2 and rng.random() < 0.5
+        f, th, l, r, p = random_tree_arrays(rng, shape, d, 2.0, 60.0, unbalanced=unb)
+        acc += -0.15 if t % 3 else -0.45
+        theta = float("-inf") if t % 5 == 4 else float(np.float32(acc))
+        M.append(wb.DTree(f, th, l, r, p), theta)
+    return M
+
+
+# ------------------------------------------------------------------------------ channels
+@pytest.mark.parametrize("case", list(small_cases()), ids=lambda c: c[0])
+def test_channel_pyramid_bit_exact_vs_reference_fixture(case):
+    name, img, info, levels = case
+    opts = dict(shrink=info["shrink"], n_per_oct=info["n_per_oct"], smooth=info["smooth"], channels=wb.channels.grad_hist)
+    got = list(wb.channels.channel_pyramid(img, opts))
+    assert len(got) == info["n_levels"]
+    for i, ((c, s), ref, rs) in enumerate(zip(got, levels, info["scales"])):
+        assert c.dtype == np.float32 and c.shape == ref.shape, (name, i)
+        assert s == rs
+        assert np.array_equal(bits(c), bits(ref)), (name, i, np.abs(c - ref).max())
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("shape", [(8, 8), (9, 23), (131, 97), (480, 640)])
+def test_channel_pyramid_vs_oracle(shape, dtype):
+    img = synth_image(shape[0], shape[1], 21, dtype)
+    if dtype == np.uint8:
+        img = np.clip(img.astype(np.int32) + 60, 0, 255).astype(np.uint8)   # bright: triggers the S2 wrap
+    o = dict(shrink=2, n_per_oct=8, smooth=1)
+    got = list(wb.channels.channel_pyramid(img, dict(o, channels=wb.channels.grad_hist)))
+    ref = list(orc.channel_pyramid(img, dict(o, channels=orc.grad_hist)))
+    assert len(got) == len(ref)
+    for (c, s), (rc, rs) in zip(got, ref):
+        assert s == rs and c.shape == rc.shape
+        assert np.array_equal(bits(c), bits(rc))
+
+
+def test_shrink4_extension_vs_oracle():
+    img = synth_image(200, 300, 5)
+    o = dict(shrink=4, n_per_oct=3, smooth=1)
+    got = list(wb.channels.channel_pyramid(img, dict(o, channels=wb.channels.grad_hist)))
+    ref = list(orc.channel_pyramid(img, dict(o, channels=orc.grad_hist)))
+    assert len(got) == len(ref) > 0
+    for (c, s), (rc, rs) in zip(got, ref):
+        assert s == rs and np.array_equal(bits(c), bits(rc))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_grad_hist_vs_oracle(dtype):
+    img = synth_image(77, 103, 9, dtype)
+    got = wb.channels.grad_hist(img)
+    ref = orc.grad_hist(img)
+    assert got.shape == ref.shape and np.array_equal(bits(got), bits(ref))
+
+
+def test_image_validation_errors():
+    with pytest.raises(TypeError):
+        list(wb.channels.channel_pyramid([[1, 2]], wb.default_channel_opts))
+    with pytest.raises(ValueError):
+        list(wb.channels.channel_pyramid(np.zeros((4, 4, 1), np.uint8), wb.default_channel_opts))
+    with pytest.raises(AssertionError):
+        list(wb.channels.channel_pyramid(np.zeros((16, 16), np.uint8), dict(wb.default_channel_opts, shrink=3)))
+    assert list(wb.channels.channel_pyramid(np.zeros((7, 40), np.uint8), wb.default_channel_opts)) == []
+
+
+# ------------------------------------------------------------------------------ cascade
+def test_cfg1_detect_vs_reference_fixture():
+    meta = golden_meta()["cfg1"]
+    g = np.load(os.path.join(GOLDEN, "cfg1_640x480.npz"))
+    M = wb.load(os.path.join(GOLDEN, "cfg1_d1_T32.pb"))
+    img = synth_image(480, 640, 0)
+    res = M.detect_raw(img)
+    det = g["det"]
+    assert M.n_loc == meta["n_loc"] and M.n_weak == meta["n_weak"]
+    assert np.array_equal(res["alive"], g["alive"])
+    assert np.array_equal(res["level"], det["level"]) and np.array_equal(res["r"], det["r"]) and np.array_equal(res["c"], det["c"])
+    assert np.array_equal(bits(res["scores"]), bits(det["score"]))
+    assert np.array_equal(bits(res["boxes"]), bits(np.stack([det["x1"], det["y1"], det["x2"], det["y2"]], 1)))
+    # the public surface: Boxes + 'scores', stats accumulate across calls
+    bx = M.detect(img)
+    assert len(bx) == det.size and np.array_equal(bx.get_field("scores"), det["score"])
+    assert M.n_loc == 2 * meta["n_loc"] and abs(M.eval_cost - meta["eval_cost"]) < 1e-12
+    M.reset()
+    assert M.n_loc == 0 and M.eval_cost == 0
+
+
+def test_mixed_depth_model_vs_reference_fixture():
+    g = np.load(os.path.join(GOLDEN, "mixed_200x264.npz"))
+    M = wb.load(os.path.join(GOLDEN, "mixed_d2_T24.pb"))
+    res = M.detect_raw(g["image"])
+    det = g["det"]
+    assert M.n_loc == int(g["n_loc"]) and M.n_weak == int(g["n_weak"])
+    assert np.array_equal(res["alive"], g["alive"])
+    assert np.array_equal(res["level"], det["level"]) and np.array_equal(res["r"], det["r"]) and np.array_equal(res["c"], det["c"])
+    assert np.array_equal(bits(res["scores"]), bits(det["score"]))
+
+
+def test_all_rejecting_stage_and_empty_model():
+    g = np.load(os.path.join(GOLDEN, "reject_200x264.npz"))
+    img = np.load(os.path.join(GOLDEN, "mixed_200x264.npz"))["image"]
+    M = wb.load(os.path.join(GOLDEN, "mixed_d2_T24.pb"))
+    R = wb.Model(M.shape, M.channel_opts)
+    for w, t in zip(M.classifier, g["theta"]):
+        R.append(w, float(t))
+    res = R.detect_raw(img)
+    assert res["scores"].size == 0 and np.array_equal(res["alive"], g["alive"])
+    assert R.n_weak == int(g["n_weak"]) and R.n_loc == int(g["n_loc"])
+
+    e = np.load(os.path.join(GOLDEN, "empty_40x56.npz"))
+    E = wb.Model((12, 12, 4), dict(wb.default_channel_opts))
+    bx = E.detect(e["image"])
+    assert np.array_equal(bx.get(), e["boxes"]) and np.array_equal(bx.get_field("scores"), e["scores"])
+    assert E.n_loc == int(e["n_loc"]) and E.n_weak == 0 and not E and len(E) == 0
+
+
+@pytest.mark.parametrize("depth,T", [(1, 7), (2, 40), (3, 21)])
+def test_detect_vs_oracle_random_models(depth, T):
+    img = synth_image(300, 420, 33 + depth)
+    M = random_model(100 + depth, T, depth)
+    res = M.detect_raw(img)
+    ref = oracle_detect(M, img)
+    assert ref["scores"].size > 0
+    assert_same_detections(res, ref)
+    assert M.n_loc == ref["n_loc"] and M.n_weak == ref["n_weak"]
+
+
+def test_detect_mixed_depths_float_image_and_odd_window():
+    img = synth_image(211, 333, 44, np.float32)
+    opts = dict(shrink=2, n_per_oct=5, smooth=1, channels=wb.channels.grad_hist)
+    M = random_model(7, 33, 2, shape=(9, 17, 4), opts=opts, mixed=True)
+    # float32 images have small channel values: rescale thresholds into range
+    for w in M.classifier:
+        w.threshold *= np.float32(1.0 / 255.0)
+    M._device = None
+    res = M.detect_raw(img)
+    ref = oracle_detect(M, img)
+    assert_same_detections(res, ref)
+
+
+def test_predict_on_image_and_tree_eval_vs_oracle():
+    rng = np.random.default_rng(5)
+    X = rng.uniform(0, 60, (70, 150, 4)).astype(np.float32)
+    M = random_model(11, 19, 2)
+    shape, _, trees, thetas = oracle_model(M)
+    rs, cs, hs, alive = M.predict_on_image_stats(X)
+    ors, ocs, ohs, oalive = orc.cascade_predict_on_image(shape, trees, thetas, X)
+    assert np.array_equal(rs, ors) and np.array_equal(cs, ocs) and np.array_equal(bits(hs), bits(ohs))
+    assert np.array_equal(alive, oalive)
+    assert M.n_loc == (70 - 12) * (150 - 12) and M.n_weak == int(oalive.sum())
+    # window smaller than the image in neither direction -> no windows
+    r2, c2, h2 = M.predict_on_image(X[:12, :40])
+    assert r2.size == 0 and h2.dtype == np.float32
+    with pytest.raises(AssertionError):
+        M.predict_on_image(X[:, :, :3])
+    # single tree on explicit positions (DTree.predict_on_image)
+    prs = rng.integers(0, 58, 1000)
+    pcs = rng.integers(0, 138, 1000)
+    for w, t in zip(M.classifier[:4], trees[:4]):
+        got = w.predict_on_image(X, prs, pcs)
+        assert np.array_equal(bits(got), bits(orc.tree_predict_on_image(t, X, prs, pcs)))
+
+
+def test_theta_scalar_kinds_follow_numpy_promotion():
+    rng = np.random.default_rng(8)
+    X = rng.uniform(0, 60, (40, 90, 4)).astype(np.float32)
+    f, th, l, r, p = random_tree_arrays(rng, (12, 12, 4), 2, 5.0, 50.0)
+    for theta in (0.1, np.float64(0.1), np.float32(0.1), np.float64(p[3]) + 1e-12, float(p[4])):
+        M = wb.Model((12, 12, 4), dict(wb.default_channel_opts))
+        M.append(wb.DTree(f, th, l, r, p), theta)
+        shape, _, trees, thetas = oracle_model(M)
+        rs, cs, hs = M.predict_on_image(X)
+        ors, ocs, ohs, _ = orc.cascade_predict_on_image(shape, trees, thetas, X)
+        assert np.array_equal(rs, ors) and np.array_equal(cs, ocs) and np.array_equal(bits(hs), bits(ohs))
+
+
+def test_1080p_depth2_128_stages_vs_oracle():
+    """BASELINE config 2 at full size against the oracle (about 10 s of CPU)."""
+    M = wb.load(os.path.join(GOLDEN, "models", "cfg2_d2_T128.pb"))
+    img = synth_image(1080, 1920, 0)
+    res = M.detect_raw(img)
+    ref = oracle_detect(M, img)
+    assert ref["n_loc"] == 3045278 == M.n_loc
+    assert_same_detections(res, ref)
+    assert M.n_weak == ref["n_weak"]

@@ -1,0 +1,41 @@
+"""Shared helpers for the tests (the oracle is imported here and only in tests/)."""
+import json
+import os
+
+import numpy as np
+
+from oracle import wb_oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_meta():
+    with open(os.path.join(GOLDEN, "golden_meta.json")) as f:
+        return json.load(f)
+
+
+def oracle_model(M):
+    """(shape, opts, trees, thetas) of a waldboost_amd.Model in the oracle's plain-array form."""
+    trees = [orc.make_tree(w.feature, w.threshold, w.left, w.right, w.prediction) for w in M.classifier]
+    opts = dict(M.channel_opts)
+    opts["channels"] = orc.grad_hist
+    return tuple(M.shape), opts, trees, list(M.theta)
+
+
+def oracle_detect(M, image):
+    shape, opts, trees, thetas = oracle_model(M)
+    return orc.detect(shape, opts, trees, thetas, image)
+
+
+def det_table(res):
+    """(level, r, c, score) rows of a detect_raw()/oracle detect() result."""
+    return np.stack([res["level"].astype(np.int64), res["r"].astype(np.int64), res["c"].astype(np.int64)], 1), res["scores"]
+
+
+def small_cases():
+    meta = golden_meta()["cases"]
+    z = np.load(os.path.join(GOLDEN, "pyramids_small.npz"))
+    for name, info in meta.items():
+        img = z[f"{name}/image"]
+        levels = [z[f"{name}/L{i}"] for i in range(info["n_levels"])]
+        yield name, img, info, levels

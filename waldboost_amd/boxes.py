@@ -1,0 +1,58 @@
+"""Minimal stand-in for the third-party ``bbx.Boxes`` container the reference returns
+(call sites: reference model.py:139,147,177,179 and __init__.py:126-130).
+
+``bbx`` is not vendored upstream and is absent here; only the members those call sites (and
+the docstring example at model.py:166-171) use are provided.  Parity at this boundary is
+unpinned upstream.
+"""
+import numpy as np
+
+
+class Boxes:
+    def __init__(self, coords, **fields):
+        self._c = np.asarray(coords).reshape(-1, 4)
+        self._fields = {k: np.asarray(v) for k, v in fields.items()}
+
+    def get(self):
+        """(N,4) array of [xmin, ymin, xmax, ymax]."""
+        return self._c
+
+    def set_field(self, name, value):
+        value = np.asarray(value)
+        if value.shape[0] != len(self):
+            raise ValueError(f"field {name!r} has {value.shape[0]} rows, boxes have {len(self)}")
+        self._fields[name] = value
+
+    def get_field(self, name):
+        return self._fields[name]
+
+    def has_field(self, name):
+        return name in self._fields
+
+    def fields(self):
+        return list(self._fields)
+
+    def normalized(self, scale=1.0):
+        return Boxes((self._c * np.float32(scale)).astype(self._c.dtype), **self._fields)
+
+    def __len__(self):
+        return self._c.shape[0]
+
+    def __getitem__(self, idx):
+        if isinstance(idx, (int, np.integer)):
+            idx = [idx]
+        return Boxes(self._c[idx], **{k: v[idx] for k, v in self._fields.items()})
+
+    def __repr__(self):
+        return f"Boxes(n={len(self)}, fields={self.fields()})"
+
+
+def concatenate(boxes, fields=None):
+    boxes = list(boxes)
+    if not boxes:
+        return Boxes(np.empty((0, 4), "f"))
+    names = list(boxes[0].fields()) if fields is None else list(fields)
+    out = Boxes(np.concatenate([b.get() for b in boxes]))
+    for n in names:
+        out._fields[n] = np.concatenate([b.get_field(n) for b in boxes])
+    return out

@@ -1,0 +1,178 @@
+// C-ABI glue: error reporting and the cascade model handle (host-side canonicalisation of the
+// reference's flat-array decision trees into the complete-tree stage records the kernels read).
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "wb_common.h"
+
+int wb_cascade_prepare(int depth, int rpw);  // wb_cascade.hip
+
+static thread_local char g_err[512] = "";
+
+void wb_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *wb_last_error(void) { return g_err; }
+extern "C" int wb_abi_version(void) { return WB_ABI_VERSION; }
+
+namespace {
+
+struct TreeView {
+    int k;  // nodes
+    const uint8_t *feature;
+    const float *threshold;
+    const int8_t *left, *right;
+    const float *prediction;
+};
+
+int tree_depth(const TreeView &t, int node) {
+    if (t.left[node] < 0) return 0;
+    int dl = tree_depth(t, t.left[node]), dr = tree_depth(t, t.right[node]);
+    return 1 + (dl > dr ? dl : dr);
+}
+
+// Fill the complete depth-D tree rooted at canonical node `ci` (BFS numbering: children of i are
+// 2i+1, 2i+2) from reference node `node`.  A reference leaf above depth D becomes a dummy split
+// (feature offset 0, both subtrees = that leaf), which cannot change the leaf value reached.
+void fill(const TreeView &t, int node, int ci, int d, int D, int rows, int pitch, int32_t *off, float *thr,
+          float *pred) {
+    const int NI = (1 << D) - 1;
+    if (d == D) {
+        pred[ci - NI] = t.prediction[node];
+        return;
+    }
+    if (t.left[node] < 0) {
+        off[ci] = 0;
+        thr[ci] = 0.0f;
+        fill(t, node, 2 * ci + 1, d + 1, D, rows, pitch, off, thr, pred);
+        fill(t, node, 2 * ci + 2, d + 1, D, rows, pitch, off, thr, pred);
+        return;
+    }
+    int fr = t.feature[node * 3 + 0], fc = t.feature[node * 3 + 1], ch = t.feature[node * 3 + 2];
+    off[ci] = (ch * rows + fr) * pitch + fc;
+    thr[ci] = t.threshold[node];
+    fill(t, t.left[node], 2 * ci + 1, d + 1, D, rows, pitch, off, thr, pred);
+    fill(t, t.right[node], 2 * ci + 2, d + 1, D, rows, pitch, off, thr, pred);
+}
+
+}  // namespace
+
+extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint8_t *feature,
+                               const float *threshold, const int8_t *left, const int8_t *right,
+                               const float *prediction, const float *theta, int m, int n, int C,
+                               WbModel **out) {
+    WB_REQUIRE(out, "wb_model_create: out is null");
+    *out = nullptr;
+    WB_REQUIRE(n_stages >= 0 && n_stages <= 16384, "wb_model_create: n_stages=%d out of range", n_stages);
+    WB_REQUIRE(m >= 1 && n >= 1 && C >= 1 && m <= 256 && n <= 256 && C <= 256,
+               "wb_model_create: window shape (%d,%d,%d) out of range (features are uint8)", m, n, C);
+    WB_REQUIRE(n_stages == 0 || (node_off && feature && threshold && left && right && prediction && theta),
+               "wb_model_create: null array");
+
+    // ---- validate the trees the way the reference walks them (training.py:84-96)
+    int D = 1;
+    std::vector<TreeView> trees((size_t)n_stages);
+    for (int s = 0; s < n_stages; ++s) {
+        int o = node_off[s], k = node_off[s + 1] - node_off[s];
+        WB_REQUIRE(o >= 0 && k >= 1 && k <= 127, "wb_model_create: stage %d has %d nodes (1..127 allowed: int8 links)", s, k);
+        TreeView t{k, feature + (size_t)o * 3, threshold + o, left + o, right + o, prediction + o};
+        for (int i = 0; i < k; ++i) {
+            if (t.left[i] < 0) continue;
+            WB_REQUIRE(t.left[i] > i && t.left[i] < k && t.right[i] > i && t.right[i] < k,
+                       "wb_model_create: stage %d node %d: children (%d,%d) must satisfy parent < child < %d",
+                       s, i, (int)t.left[i], (int)t.right[i], k);
+            WB_REQUIRE(t.feature[i * 3] < m && t.feature[i * 3 + 1] < n && t.feature[i * 3 + 2] < C,
+                       "wb_model_create: stage %d node %d: feature (%d,%d,%d) outside window (%d,%d,%d)", s, i,
+                       (int)t.feature[i * 3], (int)t.feature[i * 3 + 1], (int)t.feature[i * 3 + 2], m, n, C);
+        }
+        int d = tree_depth(t, 0);
+        if (d > D) D = d;
+        trees[s] = t;
+    }
+    if (D > WB_CASC_MAX_DEPTH) {
+        wb_set_error("wb_model_create: tree depth %d exceeds the deepest cascade kernel (%d)", D, WB_CASC_MAX_DEPTH);
+        return WB_ERR_UNSUPPORTED;
+    }
+
+    // ---- cascade tile geometry: the largest tile whose LDS footprint leaves two workgroups per CU
+    WbModel *M = new WbModel();
+    memset(M, 0, sizeof(*M));
+    M->n_stages = n_stages;
+    M->depth = D;
+    M->m = m;
+    M->n = n;
+    M->C = C;
+    M->lds_pitch = ((WB_CASC_TC + n - 1) + 3) & ~3;
+    const int budget = 80 * 1024;
+    int rpw = 8;
+    for (;; rpw >>= 1) {
+        M->rpw = rpw;
+        M->tile_rows = rpw * WB_CASC_WAVES;
+        M->lds_rows = M->tile_rows + m - 1;
+        M->lds_bytes = C * M->lds_rows * M->lds_pitch * 4 + M->tile_rows * WB_CASC_TC * 8 + n_stages * 4;
+        if (M->lds_bytes <= budget || rpw == 1) break;
+    }
+    if (M->lds_bytes > 160 * 1024) {
+        wb_set_error("wb_model_create: window (%d,%d,%d) with %d stages needs %d B of LDS (> 160 KiB)", m, n, C,
+                     n_stages, M->lds_bytes);
+        delete M;
+        return WB_ERR_UNSUPPORTED;
+    }
+    M->stage_dwords = WB_STAGE_DWORDS(D);
+
+    // ---- pack and upload the stage records
+    const int NI = (1 << D) - 1, NL = 1 << D, SD = M->stage_dwords;
+    std::vector<int32_t> packed((size_t)n_stages * SD, 0);
+    for (int s = 0; s < n_stages; ++s) {
+        int32_t *rec = packed.data() + (size_t)s * SD;
+        int32_t *off = rec;
+        float *thr = reinterpret_cast<float *>(rec + NI);
+        float *pred = reinterpret_cast<float *>(rec + 2 * NI);
+        fill(trees[s], 0, 0, 0, D, M->lds_rows, M->lds_pitch, off, thr, pred);
+        reinterpret_cast<float *>(rec)[2 * NI + NL] = theta[s];
+    }
+    if (n_stages > 0) {
+        hipError_t e = hipMalloc((void **)&M->stages_dev, packed.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(M->stages_dev, packed.data(), packed.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            wb_set_error("wb_model_create: uploading %zu stage bytes failed: %s", packed.size() * 4, hipGetErrorString(e));
+            if (M->stages_dev) (void)hipFree(M->stages_dev);
+            delete M;
+            return WB_ERR_HIP;
+        }
+    }
+    int rc = wb_cascade_prepare(D, M->rpw);
+    if (rc != WB_OK) {
+        if (M->stages_dev) (void)hipFree(M->stages_dev);
+        delete M;
+        return rc;
+    }
+    *out = M;
+    return WB_OK;
+}
+
+extern "C" int wb_model_destroy(WbModel *model) {
+    if (!model) return WB_OK;
+    if (model->stages_dev) (void)hipFree(model->stages_dev);
+    delete model;
+    return WB_OK;
+}
+
+extern "C" int wb_model_info(const WbModel *model, WbModelInfo *info) {
+    WB_REQUIRE(model && info, "wb_model_info: null pointer");
+    info->n_stages = model->n_stages;
+    info->depth = model->depth;
+    info->m = model->m;
+    info->n = model->n;
+    info->C = model->C;
+    info->tile_rows = model->tile_rows;
+    info->tile_cols = WB_CASC_TC;
+    info->lds_bytes = model->lds_bytes;
+    return WB_OK;
+}

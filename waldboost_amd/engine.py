@@ -1,0 +1,289 @@
+"""Device-side execution of the hot path: buffers, launches, hipGraph capture.
+
+``PyramidEngine`` owns the HBM-resident state of one (image shape, dtype, channel_opts,
+batch) configuration and drives the three kernel groups through the C ABI:
+
+    octaves (wb_octaves_launch) -> channels (wb_channels_launch) -> cascade (wb_cascade_launch)
+
+torch is used only for device memory, streams and graph capture; all compute is in
+csrc/*.hip.  Nothing here falls back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+from .plan import PyramidPlan, N_CHANNELS
+
+_TORCH_DT = {}
+
+
+def _torch_dtype(np_dtype):
+    import torch
+    if not _TORCH_DT:
+        _TORCH_DT.update({np.dtype(np.uint8): torch.uint8, np.dtype(np.float32): torch.float32})
+    try:
+        return _TORCH_DT[np.dtype(np_dtype)]
+    except KeyError:
+        raise NotImplementedError(
+            f"image dtype {np.dtype(np_dtype)} has no HIP kernel (uint8 and float32 are supported)") from None
+
+
+def orientation_constants():
+    """cos/sin of the 4 unsigned orientations, built exactly as reference channels.py:43-46
+    builds them (NumPy fp64; note cos(pi/2) = 6.1e-17, not 0)."""
+    theta = np.linspace(0, np.pi, N_CHANNELS + 1)
+    return np.concatenate([np.cos(theta[:-1]), np.sin(theta[:-1])]).astype(np.float64)
+
+
+def theta_as_f32(theta):
+    """The fp32 value t such that ``hs >= theta`` (NumPy-2 promotion) == ``hs >= t`` for every
+    fp32 ``hs``.  Python floats are weak scalars (rounded to fp32 by NumPy); NumPy fp64/int
+    scalars force an fp64 comparison, which equals comparing with the smallest fp32 >= theta."""
+    if isinstance(theta, (np.float32, np.float16)):
+        return np.float32(theta)
+    if type(theta) in (float, int, bool):
+        with np.errstate(over="ignore"):
+            return np.float32(theta)
+    t64 = np.float64(theta)
+    if np.isnan(t64):
+        return np.float32(np.nan)
+    with np.errstate(over="ignore"):
+        t32 = np.float32(t64)
+    if np.float64(t32) < t64:
+        t32 = np.nextafter(t32, np.float32(np.inf))
+    return t32
+
+
+class DeviceCascade:
+    """A WbModel handle built from the Python-side stage list (immutable snapshot)."""
+
+    def __init__(self, shape, classifier, theta):
+        lib = nat.load()
+        nat.require_gpu()
+        m, n, Cc = (int(x) for x in shape)
+        T = len(classifier)
+        node_off = np.zeros(T + 1, np.int32)
+        for i, w in enumerate(classifier):
+            node_off[i + 1] = node_off[i] + w.left.size
+        cat = lambda name, dt: (np.ascontiguousarray(np.concatenate([getattr(w, name).reshape(-1) for w in classifier]).astype(dt))
+                                if T else np.zeros(0, dt))
+        feature = cat("feature", np.uint8)
+        threshold = cat("threshold", np.float32)
+        left = cat("left", np.int8)
+        right = cat("right", np.int8)
+        pred = cat("prediction", np.float32)
+        th = np.array([theta_as_f32(t) for t in theta], np.float32)
+        h = C.c_void_p()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        nat.check(lib.wb_model_create(T, vp(node_off), vp(feature), vp(threshold), vp(left), vp(right), vp(pred),
+                                      vp(th), m, n, Cc, C.byref(h)), "wb_model_create")
+        self.handle = h
+        self._lib = lib
+        info = nat.WbModelInfo()
+        nat.check(lib.wb_model_info(h, C.byref(info)), "wb_model_info")
+        self.n_stages, self.depth = info.n_stages, info.depth
+        self.m, self.n, self.C = info.m, info.n, info.C
+        self.tile_rows, self.tile_cols, self.lds_bytes = info.tile_rows, info.tile_cols, info.lds_bytes
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.wb_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class PyramidEngine:
+    def __init__(self, H, W, dtype, shrink, n_per_oct, smooth, batch=1, layout=nat.WB_LAYOUT_PLANAR,
+                 exact_single=False, det_capacity=1 << 18):
+        import torch
+        self.lib = nat.load()
+        self.dev = nat.require_gpu()
+        self.dtype = np.dtype(dtype)
+        self.tdtype = _torch_dtype(dtype)
+        self.wb_dtype = nat.WB_DTYPE_U8 if self.dtype == np.uint8 else nat.WB_DTYPE_F32
+        self.batch = int(batch)
+        self.layout = layout
+        self.plan = PyramidPlan(H, W, shrink, n_per_oct, smooth, exact_single=exact_single)
+        self.exact_single = exact_single
+        p = self.plan
+        dev = self.dev
+        self.img = torch.empty((self.batch, p.H, p.W), dtype=self.tdtype, device=dev)
+        self.oct = torch.empty((self.batch, p.oct_total), dtype=self.tdtype, device=dev)
+        self.minmax = torch.zeros((self.batch, max(p.n_oct, 1), 2), dtype=torch.int32, device=dev)
+        table, total = p.level_table(layout)
+        self.chn_stride = int(total)
+        self.level_np = table
+        self.levels = torch.from_numpy(table.view(np.uint8).copy()).to(dev) if p.n_levels else None
+        tiles = p.chan_tiles()
+        self.n_chan_tiles = int(tiles.size)
+        self.chan_tiles = torch.from_numpy(tiles.view(np.uint8).copy()).to(dev) if tiles.size else None
+        # zero-filled once: planar row padding [v, vp) is never written and must stay finite
+        self.chn = torch.zeros((self.batch, self.chn_stride), dtype=torch.float32, device=dev)
+        self.cs_sn = orientation_constants()
+        self._oct_off = (C.c_int64 * max(p.n_oct, 1))(*[int(x) for x in p.oct_off[:max(p.n_oct, 1)]])
+        self.det_capacity = int(det_capacity)
+        self.det = torch.empty((self.det_capacity, 4), dtype=torch.int32, device=dev)
+        self.det_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.alive = None
+        self._casc = {}
+        if exact_single:
+            # grad_hist on a bare image: no resize happens, so the clip range is (-inf, +inf)
+            lo = np.array([nat_f32_key(-np.inf)], np.uint32).view(np.int32)[0]
+            hi = np.array([nat_f32_key(np.inf)], np.uint32).view(np.int32)[0]
+            if self.wb_dtype == nat.WB_DTYPE_U8:
+                lo, hi = 0, 255
+            self.minmax[:, :, 0] = int(lo)
+            self.minmax[:, :, 1] = int(hi)
+
+    # ------------------------------------------------------------------ input
+    def load_images(self, images):
+        """images: ndarray / tensor [B,H,W] (or [H,W]) of the engine's dtype."""
+        import torch
+        if isinstance(images, np.ndarray):
+            if images.dtype != self.dtype:
+                raise TypeError(f"engine built for {self.dtype} images, got {images.dtype}")
+            t = torch.from_numpy(np.ascontiguousarray(images))
+        else:
+            t = images
+        if t.dim() == 2:
+            t = t[None]
+        if tuple(t.shape) != (self.batch, self.plan.H, self.plan.W):
+            raise ValueError(f"expected images of shape {(self.batch, self.plan.H, self.plan.W)}, got {tuple(t.shape)}")
+        self.img.copy_(t, non_blocking=True)
+
+    # ------------------------------------------------------------------ launches
+    def run_channels(self):
+        p = self.plan
+        if p.n_levels == 0:
+            return
+        lib, st = self.lib, nat.stream_ptr()
+        if not self.exact_single:
+            nat.check(lib.wb_octaves_launch(st, nat.ptr(self.img), self.wb_dtype, self.batch, p.H, p.W,
+                                            p.H * p.W, nat.ptr(self.oct), p.oct_total, self._oct_off, p.n_oct,
+                                            nat.ptr(self.minmax)), "wb_octaves_launch")
+        nat.check(lib.wb_channels_launch(st, nat.ptr(self.img), p.H * p.W, nat.ptr(self.oct), p.oct_total,
+                                         self.wb_dtype, self.batch, nat.ptr(self.levels), p.n_levels,
+                                         nat.ptr(self.chan_tiles), self.n_chan_tiles, nat.ptr(self.minmax),
+                                         max(p.n_oct, 1), p.shrink, p.smooth,
+                                         self.cs_sn.ctypes.data_as(C.POINTER(C.c_double)), nat.ptr(self.chn),
+                                         self.chn_stride, self.layout), "wb_channels_launch")
+
+    def _casc_state(self, dm):
+        import torch
+        key = id(dm)
+        stt = self._casc.get(key)
+        if stt is None:
+            tiles = self.plan.casc_tiles(dm.m, dm.n, dm.tile_rows, dm.tile_cols)
+            stt = dict(
+                dm=dm, n_tiles=int(tiles.size),
+                tiles=torch.from_numpy(tiles.view(np.uint8).copy()).to(self.dev) if tiles.size else None,
+                alive=torch.zeros((self.batch, max(self.plan.n_levels, 1), max(dm.n_stages, 1)),
+                                  dtype=torch.int32, device=self.dev))
+            self._casc = {key: stt}          # one cascade resident per engine
+        return stt
+
+    def run_cascade(self, dm):
+        """Zero the counters and scan every level of every image with cascade `dm`."""
+        stt = self._casc_state(dm)
+        self.det_count.zero_()
+        stt["alive"].zero_()
+        if stt["n_tiles"] == 0:
+            return stt
+        nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.chn), self.chn_stride,
+                                             self.layout, self.batch, nat.ptr(self.levels), self.plan.n_levels,
+                                             nat.ptr(stt["tiles"]), stt["n_tiles"], nat.ptr(self.det),
+                                             nat.ptr(self.det_count), self.det_capacity, nat.ptr(stt["alive"])),
+                  "wb_cascade_launch")
+        return stt
+
+    def run(self, dm):
+        self.run_channels()
+        return self.run_cascade(dm)
+
+    # ------------------------------------------------------------------ hipGraph
+    def capture(self, dm):
+        """Capture octaves -> channels -> cascade into one hipGraph (torch.cuda.CUDAGraph on ROCm).
+        Returns the graph; ``graph.replay()`` re-runs the whole pipeline on the resident images."""
+        import torch
+        self._casc_state(dm)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.run(dm)                      # warm-up outside capture (module load, attributes)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run(dm)
+        return g
+
+    # ------------------------------------------------------------------ results
+    def ensure_capacity(self, dm):
+        """Re-run the cascade with a larger record buffer if the last scan overflowed it."""
+        import torch
+        n = int(self.det_count.item()) & 0xFFFFFFFF
+        while n > self.det_capacity:
+            self.det_capacity = int(n * 1.25) + 1024
+            self.det = torch.empty((self.det_capacity, 4), dtype=torch.int32, device=self.dev)
+            self.run_cascade(dm)
+            n = int(self.det_count.item()) & 0xFFFFFFFF
+        return n
+
+    def sorted_detections(self, n):
+        """First n records ordered by (image, level, r, c) -- the reference's output order
+        (row-major window grid, levels in pyramid order)."""
+        import torch
+        d = self.det[:n]
+        if n == 0:
+            return d
+        rc = d[:, 2].to(torch.int64) & 0xFFFFFFFF
+        key = (d[:, 0].to(torch.int64) << 44) | (d[:, 1].to(torch.int64) << 32) | ((rc & 0xFFFF) << 16) | (rc >> 16)
+        order = torch.argsort(key)
+        return d[order].contiguous()
+
+    def boxes(self, det_sorted, dm):
+        import torch
+        n = det_sorted.shape[0]
+        boxes = torch.empty((n, 4), dtype=torch.float32, device=self.dev)
+        scores = torch.empty(n, dtype=torch.float32, device=self.dev)
+        if n:
+            inv = np.array([np.float32(1.0 / s) for s in self.plan.scales], np.float32)
+            inv_d = torch.from_numpy(inv).to(self.dev)
+            nat.check(self.lib.wb_boxes_launch(nat.stream_ptr(), nat.ptr(det_sorted), n, nat.ptr(inv_d), dm.m, dm.n,
+                                               nat.ptr(boxes), nat.ptr(scores)), "wb_boxes_launch")
+        return boxes, scores
+
+    def read_level(self, b, l):
+        """Channels of level l of image b as a fresh HWC float32 ndarray [u,v,4]."""
+        lv = self.plan.levels[l]
+        off = int(self.level_np[l]["chn_off"])
+        u, v, vp = lv["u"], lv["v"], lv["vp"]
+        if self.layout == nat.WB_LAYOUT_HWC:
+            return self.chn[b, off:off + u * v * N_CHANNELS].reshape(u, v, N_CHANNELS).cpu().numpy()
+        t = self.chn[b, off:off + N_CHANNELS * u * vp].reshape(N_CHANNELS, u, vp)[:, :, :v]
+        return t.permute(1, 2, 0).contiguous().cpu().numpy()
+
+
+def nat_f32_key(f):
+    b = np.array([f], np.float32).view(np.uint32)[0]
+    return np.uint32(~b & 0xFFFFFFFF) if (b & 0x80000000) else np.uint32(b | 0x80000000)
+
+
+_ENGINES = {}
+
+
+def get_engine(H, W, dtype, shrink, n_per_oct, smooth, batch=1, layout=nat.WB_LAYOUT_PLANAR, exact_single=False):
+    """Small cache of engines keyed by configuration (buffers are reused across calls)."""
+    import torch
+    key = (int(H), int(W), np.dtype(dtype).str, int(shrink), int(n_per_oct), int(smooth), int(batch), int(layout),
+           bool(exact_single), torch.cuda.current_device() if torch.cuda.is_available() else -1)
+    e = _ENGINES.get(key)
+    if e is None:
+        if len(_ENGINES) >= 4:
+            _ENGINES.pop(next(iter(_ENGINES)))
+        e = PyramidEngine(H, W, dtype, shrink, n_per_oct, smooth, batch, layout, exact_single)
+        _ENGINES[key] = e
+    return e

@@ -1,0 +1,281 @@
+"""Detection model -- drop-in for ``waldboost.model.Model`` on the detection path
+(reference model.py:32-344): same constructor, ``append``/iteration, ``detect``,
+``predict_on_image``, ``channels``, ``scan_channels``, ``get_boxes``, ``eval_cost``/``reset``
+and the zlib+protobuf ``.pb`` format.  The dense cascade scan runs in csrc/wb_cascade.hip.
+"""
+import zlib
+
+import numpy as np
+from google.protobuf.message import DecodeError
+
+from . import _native as nat
+from . import channels as _channels
+from . import engine as _engine
+from . import model_pb2
+from .boxes import Boxes, concatenate
+from .channels import channel_pyramid
+from .training import DTree
+
+# the name written into .pb files for our grad_hist, so that the reference can load them too
+_REFERENCE_NAME = "waldboost.channels.grad_hist"
+
+
+def symbol_name(s):
+    if _channels.is_grad_hist(s):
+        return _REFERENCE_NAME
+    return s.__module__ + "." + s.__qualname__
+
+
+def symbol_from_name(name: str):
+    """Allow-list replacement of the reference's eval-based lookup (model.py:27-29)."""
+    try:
+        return _channels.CHANNEL_FUNCS[name]
+    except KeyError:
+        raise ValueError(f"unknown channel function {name!r} in model file "
+                         f"(known: {sorted(_channels.CHANNEL_FUNCS)})") from None
+
+
+class Model:
+    def __init__(self, shape, channel_opts):
+        self.shape = shape
+        self.channel_opts = channel_opts
+        self.classifier = []
+        self.theta = []
+        self._device = None
+        self.reset()
+
+    # ---- statistics (reference model.py:69-89)
+    @property
+    def eval_cost(self):
+        return self.n_weak / self.n_loc if self.n_loc > 0 else 0
+
+    def reset(self):
+        self.n_loc = 0
+        self.n_weak = 0
+
+    # ---- container (reference model.py:91-92, 261-283)
+    def __getitem__(self, i):
+        return self.classifier[i], self.theta[i]
+
+    def __len__(self):
+        return len(self.classifier)
+
+    def __bool__(self):
+        return bool(self.classifier)
+
+    def __iter__(self):
+        yield from zip(self.classifier, self.theta)
+
+    def append(self, weak, theta):
+        self.classifier.append(weak)
+        self.theta.append(theta)
+        self._device = None
+
+    def device_cascade(self):
+        """The device-side cascade for the current stage list (rebuilt after ``append``)."""
+        sig = (len(self.classifier), tuple(self.shape))
+        if self._device is None or self._device[0] != sig:
+            self._device = (sig, _engine.DeviceCascade(self.shape, self.classifier, self.theta))
+        return self._device[1]
+
+    # ---- pyramid (reference model.py:95-134)
+    def channels(self, image):
+        yield from channel_pyramid(image, self.channel_opts)
+
+    def scan_channels(self, image):
+        yield from ((chns, scale, self.predict_on_image(chns)) for chns, scale in self.channels(image))
+
+    def get_boxes(self, r, c, scale) -> Boxes:
+        """XYXY boxes of window origins (r, c) at pyramid scale `scale` (reference model.py:136-147)."""
+        r = np.asarray(r)
+        c = np.asarray(c)
+        if r.size == 0:
+            return Boxes(np.empty((0, 4), "f"))
+        m, n = self.shape[:2]
+        x1 = c.reshape(-1, 1)
+        y1 = r.reshape(-1, 1)
+        rects = np.concatenate([x1, y1, x1 + n, y1 + m], axis=1).astype(np.float32)
+        return Boxes(rects).normalized(scale=1.0 / scale)
+
+    # ---- the cascade on one channel image (reference model.py:216-259)
+    def predict_on_image(self, X):
+        """All windows of X[u,v,C] through the cascade -> (rs, cs, hs) of the survivors in
+        row-major order; updates n_loc / n_weak."""
+        rs, cs, hs, alive = self.predict_on_image_stats(X)
+        return rs, cs, hs
+
+    def predict_on_image_stats(self, X):
+        """As predict_on_image, plus alive[t] = windows entering stage t."""
+        import torch
+        u, v, ch_image = X.shape
+        m, n, ch_cls = self.shape
+        assert ch_image == ch_cls, f"Invalid number of channels. Expected {ch_cls} given {ch_image}."
+        dm = self.device_cascade()
+        eng = _SingleLevel.get(u, v, ch_image)
+        eng.load(X)
+        n_det, alive = eng.scan(dm)
+        self.n_loc += max(u - m, 0) * max(v - n, 0)
+        self.n_weak += int(alive.sum())
+        det = eng.sorted(n_det)
+        if n_det == 0:
+            return np.empty(0, np.int64), np.empty(0, np.int64), np.empty(0, np.float32), alive
+        d = det.cpu().numpy().view(nat.DET_DTYPE).reshape(-1)
+        return d["r"].astype(np.int64), d["c"].astype(np.int64), d["score"].copy(), alive
+
+    # ---- whole-image detection (reference model.py:149-179)
+    def detect(self, image) -> Boxes:
+        """Detect objects in a 2-D image; returns Boxes with a 'scores' field, levels in pyramid
+        order and windows in row-major order within a level, like the reference."""
+        res = self.detect_raw(image)
+        out = Boxes(res["boxes"])
+        out.set_field("scores", res["scores"])
+        return out
+
+    def detect_raw(self, image):
+        """detect() with everything the parity tests compare: boxes, scores, (level, r, c),
+        alive[level, stage]; updates n_loc / n_weak."""
+        _channels._validate_image(image)
+        shrink, n_per_oct, smooth = _channels.read_opts(self.channel_opts)
+        m, n, Cc = self.shape
+        assert Cc == 4, f"Invalid number of channels. Expected {Cc} given 4."
+        H, W = image.shape
+        dm = self.device_cascade()
+        eng = _engine.get_engine(H, W, image.dtype, shrink, n_per_oct, smooth, 1, nat.WB_LAYOUT_PLANAR)
+        T = len(self)
+        if eng.plan.n_levels == 0:
+            return dict(boxes=np.empty((0, 4), "f"), scores=np.empty(0, "f"), level=np.empty(0, np.int32),
+                        r=np.empty(0, np.int64), c=np.empty(0, np.int64), alive=np.zeros((0, T), np.int64),
+                        scales=[])
+        eng.load_images(image)
+        stt = eng.run(dm)
+        n_det = eng.ensure_capacity(dm)
+        det = eng.sorted_detections(n_det)
+        boxes, scores = eng.boxes(det, dm)
+        alive = stt["alive"][0, :, :T].cpu().numpy().astype(np.int64).reshape(eng.plan.n_levels, T)
+        self.n_loc += eng.plan.n_loc(m, n)
+        self.n_weak += int(alive.sum())
+        d = det.cpu().numpy().view(nat.DET_DTYPE).reshape(-1)
+        return dict(boxes=boxes.cpu().numpy(), scores=scores.cpu().numpy(), level=d["level"].copy(),
+                    r=d["r"].astype(np.int64), c=d["c"].astype(np.int64), alive=alive, scales=list(eng.plan.scales))
+
+    def predict(self, X):
+        raise NotImplementedError("Model.predict (per-sample mode used by training) is outside the detection hot path")
+
+    # ---- wire format (reference model.py:285-344)
+    def as_proto(self, proto):
+        proto.Clear()
+        proto.shape.extend(int(x) for x in self.shape)
+        proto.channel_opts.shrink = self.channel_opts["shrink"]
+        proto.channel_opts.n_per_oct = self.channel_opts["n_per_oct"]
+        proto.channel_opts.smooth = self.channel_opts["smooth"]
+        proto.channel_opts.func = symbol_name(self.channel_opts["channels"])
+        for weak, theta in self:
+            w_pb = proto.classifier.add()
+            weak.as_proto(w_pb)
+            proto.theta.append(float(theta))
+
+    @staticmethod
+    def from_proto(proto):
+        shape = tuple(proto.shape)
+        channel_opts = {
+            "shrink": proto.channel_opts.shrink,
+            "n_per_oct": proto.channel_opts.n_per_oct,
+            "smooth": proto.channel_opts.smooth,
+            "channels": symbol_from_name(proto.channel_opts.func),
+        }
+        M = Model(shape, channel_opts)
+        for weak_proto, theta_proto in zip(proto.classifier, proto.theta):
+            M.append(DTree.from_proto(weak_proto), theta_proto)
+        return M
+
+    def save(self, filename):
+        proto = model_pb2.Model()
+        self.as_proto(proto)
+        data = zlib.compress(proto.SerializeToString(), 9)
+        with open(filename, "wb") as f:
+            f.write(data)
+
+    @staticmethod
+    def load(filename):
+        with open(filename, "rb") as f:
+            data = f.read()
+        proto = model_pb2.Model()
+        try:
+            data = zlib.decompress(data)
+            proto.ParseFromString(data)
+        except (DecodeError, zlib.error):
+            raise ValueError(f"Cannot read model from {filename}")
+        return Model.from_proto(proto)
+
+
+class _SingleLevel:
+    """Device state for Model.predict_on_image on a caller-supplied HWC channel image."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, u, v, C):
+        import torch
+        key = (u, v, C, torch.cuda.current_device() if torch.cuda.is_available() else -1)
+        e = cls._cache.get(key)
+        if e is None:
+            if len(cls._cache) >= 8:
+                cls._cache.pop(next(iter(cls._cache)))
+            e = cls._cache[key] = cls(u, v, C)
+        return e
+
+    def __init__(self, u, v, C):
+        import torch
+        self.lib = nat.load()
+        self.dev = nat.require_gpu()
+        if u >= 65536 or v >= 65536:
+            raise ValueError("channel image larger than 65535 pixels per side")
+        self.u, self.v, self.C = u, v, C
+        t = np.zeros(1, nat.LEVEL_DTYPE)
+        t[0]["u"], t[0]["v"], t[0]["vp"], t[0]["chn_off"] = u, v, v, 0
+        self.levels = torch.from_numpy(t.view(np.uint8).copy()).to(self.dev)
+        self.X = torch.empty((max(u * v * C, 1),), dtype=torch.float32, device=self.dev)
+        self.capacity = 1 << 16
+        self.det = torch.empty((self.capacity, 4), dtype=torch.int32, device=self.dev)
+        self.count = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._tiles = {}
+
+    def load(self, X):
+        import torch
+        if isinstance(X, torch.Tensor):
+            self.X[:self.u * self.v * self.C].copy_(X.to(torch.float32).reshape(-1))
+        else:
+            self.X[:self.u * self.v * self.C].copy_(torch.from_numpy(np.ascontiguousarray(X, np.float32).reshape(-1)))
+
+    def scan(self, dm):
+        import torch
+        from .plan import PyramidPlan
+        key = (dm.m, dm.n, dm.tile_rows, dm.tile_cols)
+        if key not in self._tiles:
+            tl = PyramidPlan._tiles([(max(self.u - dm.m, 0), max(self.v - dm.n, 0))], dm.tile_rows, dm.tile_cols)
+            self._tiles = {key: (int(tl.size), torch.from_numpy(tl.view(np.uint8).copy()).to(self.dev) if tl.size else None)}
+        n_tiles, tiles = self._tiles[key]
+        T = dm.n_stages
+        alive = torch.zeros((1, 1, max(T, 1)), dtype=torch.int32, device=self.dev)
+        while True:
+            self.count.zero_()
+            alive.zero_()
+            if n_tiles:
+                nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.X), 0, nat.WB_LAYOUT_HWC,
+                                                     1, nat.ptr(self.levels), 1, nat.ptr(tiles), n_tiles,
+                                                     nat.ptr(self.det), nat.ptr(self.count), self.capacity,
+                                                     nat.ptr(alive)), "wb_cascade_launch")
+            n = int(self.count.item()) & 0xFFFFFFFF
+            if n <= self.capacity:
+                break
+            self.capacity = int(n * 1.25) + 1024
+            self.det = torch.empty((self.capacity, 4), dtype=torch.int32, device=self.dev)
+        return n, alive[0, 0, :T].cpu().numpy().astype(np.int64)
+
+    def sorted(self, n):
+        import torch
+        d = self.det[:n]
+        if n == 0:
+            return d
+        rc = d[:, 2].to(torch.int64) & 0xFFFFFFFF
+        key = ((rc & 0xFFFF) << 16) | (rc >> 16)
+        return d[torch.argsort(key)].contiguous()

@@ -1,0 +1,156 @@
+"""Host-side pyramid plan: octaves, level table, tile tables, HBM layout.
+
+The level plan is Python-float arithmetic in the reference (channels.py:124-131) and is
+reproduced here expression by expression -- it is never re-derived in C floats.
+Everything in this module is NumPy/pure Python and runs without a GPU.
+
+HBM layout per image (one contiguous buffer each, images of a batch at a fixed stride):
+  octaves   : octave k>=1 at element offset oct_off[k] (octave 0 is the image itself)
+  channels  : level l at float offset chn_off[l];  planar [4][u][vp] (vp = v rounded up to 4
+              floats so that every row start is 16-byte aligned for the cascade's float4
+              tile loads) or HWC [u][v][4] (what channel_pyramid hands to callers)
+"""
+import math
+
+import numpy as np
+
+from ._native import LEVEL_DTYPE, TILE_DTYPE, WB_LAYOUT_HWC, WB_LAYOUT_PLANAR
+
+N_CHANNELS = 4          # grad_hist with n_bins=4 (reference channels.py:40)
+CHAN_TILES = {1: (16, 64), 2: (16, 64), 4: (8, 32)}   # must match wb_channels_tile()
+
+
+def octave_shapes(H, W):
+    """reference channels.py:93-101: halve (dropping odd tails) until w<8 or h<8."""
+    out = []
+    h, w = int(H), int(W)
+    while not (w < 8 or h < 8):
+        out.append((h, w))
+        h, w = h // 2, w // 2
+    return out
+
+
+def xcd_order(n):
+    """Permutation p so that workgroups b, b+8, b+16, ... (which share an XCD and its L2 under
+    round-robin dispatch) receive consecutive entries of the natural tile order."""
+    q, r = divmod(n, 8)
+    b = np.arange(n)
+    x = b % 8
+    start = np.where(x < r, x * (q + 1), r * (q + 1) + (x - r) * q)
+    return start + b // 8
+
+
+class PyramidPlan:
+    def __init__(self, H, W, shrink, n_per_oct, smooth=1, exact_single=False):
+        assert shrink in (1, 2, 4), "Shrink factor must be 1 or 2 (4 is a documented extension)"
+        self.H, self.W = int(H), int(W)
+        self.shrink, self.n_per_oct, self.smooth = int(shrink), int(n_per_oct), int(smooth)
+        self.octaves = octave_shapes(H, W)
+        self.n_oct = len(self.octaves)
+        off, acc = [], 0
+        for k, (h, w) in enumerate(self.octaves):
+            off.append(acc if k else 0)
+            if k:
+                acc += h * w
+        self.oct_off = np.array(off, np.int64)
+        self.oct_total = max(acc, 1)
+
+        levels = []
+        if exact_single:
+            # one level at the image's own size (grad_hist on a bare image: no resize rounding)
+            levels.append(dict(oct=0, h=self.H, w=self.W, nh=self.H, nw=self.W, scale=1.0))
+            self.octaves = [(self.H, self.W)]
+            self.n_oct = 1
+        else:
+            factor = 2 ** (-1 / n_per_oct)
+            for o, (h, w) in enumerate(self.octaves):
+                for i in range(n_per_oct):
+                    s = factor ** i
+                    nw, nh = int((w * s) / shrink) * shrink, int((h * s) / shrink) * shrink
+                    real_scale = nw / self.W
+                    levels.append(dict(oct=o, h=h, w=w, nh=nh, nw=nw, scale=real_scale / shrink))
+        for lv in levels:
+            lv["u"], lv["v"] = lv["nh"] // shrink, lv["nw"] // shrink
+            lv["vp"] = (lv["v"] + 3) // 4 * 4
+            if lv["u"] >= 65536 or lv["v"] >= 65536:
+                raise ValueError("channel image larger than 65535 pixels per side")
+        self.levels = levels
+        self.n_levels = len(levels)
+        self.scales = [lv["scale"] for lv in levels]
+
+        self._tables = {}
+        self._chan_tiles = None
+
+    # ------------------------------------------------------------------ layout
+    def chn_offsets(self, layout):
+        offs, acc = [], 0
+        for lv in self.levels:
+            offs.append(acc)
+            if layout == WB_LAYOUT_PLANAR:
+                acc += N_CHANNELS * lv["u"] * lv["vp"]
+            else:
+                acc += N_CHANNELS * lv["u"] * lv["v"]
+        return offs, max(acc, 4)
+
+    def level_table(self, layout):
+        if layout not in self._tables:
+            offs, total = self.chn_offsets(layout)
+            t = np.zeros(self.n_levels, LEVEL_DTYPE)
+            for i, lv in enumerate(self.levels):
+                t[i]["oct"] = lv["oct"]
+                t[i]["src_h"], t[i]["src_w"] = lv["h"], lv["w"]
+                t[i]["nh"], t[i]["nw"] = lv["nh"], lv["nw"]
+                t[i]["u"], t[i]["v"], t[i]["vp"] = lv["u"], lv["v"], lv["vp"]
+                t[i]["src_off"] = self.oct_off[lv["oct"]]
+                t[i]["chn_off"] = offs[i]
+                # scipy zoom recomputes the step from the integer shapes in fp64
+                t[i]["sy"] = np.float64(lv["h"]) / np.float64(lv["nh"])
+                t[i]["sx"] = np.float64(lv["w"]) / np.float64(lv["nw"])
+            self._tables[layout] = (t, total)
+        return self._tables[layout]
+
+    # ------------------------------------------------------------------ tiles
+    @staticmethod
+    def _tiles(dims, tr, tc):
+        """dims: per level (rows, cols) to cover with tr x tc tiles; natural order, XCD-permuted."""
+        parts = []
+        for l, (r, c) in enumerate(dims):
+            if r <= 0 or c <= 0:
+                continue
+            ny, nx = -(-r // tr), -(-c // tc)
+            ty, tx = np.divmod(np.arange(ny * nx), nx)
+            a = np.zeros(ny * nx, TILE_DTYPE)
+            a["level"], a["ty"], a["tx"] = l, ty, tx
+            parts.append(a)
+        if not parts:
+            return np.zeros(0, TILE_DTYPE)
+        nat = np.concatenate(parts)
+        return nat[xcd_order(nat.size)]
+
+    def chan_tiles(self):
+        if self._chan_tiles is None:
+            tu, tv = CHAN_TILES[self.shrink]
+            self._chan_tiles = self._tiles([(lv["u"], lv["v"]) for lv in self.levels], tu, tv)
+        return self._chan_tiles
+
+    def window_grid(self, m, n):
+        """(u-m) x (v-n) windows per level -- one row and one column fewer than geometrically
+        valid, exactly like reference model.py:243."""
+        return [(max(lv["u"] - m, 0), max(lv["v"] - n, 0)) for lv in self.levels]
+
+    def casc_tiles(self, m, n, tile_rows, tile_cols):
+        return self._tiles(self.window_grid(m, n), tile_rows, tile_cols)
+
+    def n_loc(self, m, n):
+        return int(sum(r * c for r, c in self.window_grid(m, n)))
+
+    # ------------------------------------------------------------------ roofline arithmetic
+    def algorithmic_bytes(self, px_bytes):
+        """Per image, SURVEY section 8(d): image read + octave writes + per-level source reads
+        + channel write (+ the same bytes again for the cascade's read)."""
+        img = self.H * self.W * px_bytes
+        octw = sum(h * w for h, w in self.octaves[1:]) * px_bytes
+        src = sum(lv["h"] * lv["w"] for lv in self.levels) * px_bytes
+        chn = sum(lv["u"] * lv["v"] for lv in self.levels) * N_CHANNELS * 4
+        return dict(image=img, octaves=octw, level_src=src, chn_write=chn, chn_read=chn,
+                    channels_kernel=src + chn, cascade_kernel=chn, total=img + octw + src + 2 * chn)
