@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Benchmark of the waldboost detection hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+A *step* is one pass of the hot path -- octave pyramid, fused grad_hist channel pyramid and the
+dense 128-stage depth-2 cascade scan (BASELINE.json configs[1]) -- over one batch of B synthetic
+1920x1080 uint8 images already resident in HBM, replayed from one hipGraph.  Consecutive steps
+cycle through a pool of different resident images.  With N>1 (launched by torch.distributed.run,
+one rank per GPU) every rank runs the same per-GPU workload on its own images ("weak" scaling)
+and each step ends with the RCCL all-gather of the fixed-size detection prefix, issued on a side
+stream so it overlaps the next step's kernels.
+
+Rank 0 prints ONE JSON line: candidate windows/s (whole job), plus
+  roofline     -- the dominant kernel's algorithmic HBM bytes per launch / its average launch
+                  duration (HIP events on the launch stream) against the 8 TB/s HBM peak
+  cpu_baseline -- the NumPy oracle (CPU restatement of the reference) on a bounded sample of
+                  the same workload, multiprocessing.Pool over images like the reference's
+                  scripts/waldboost-detect.py:64-67
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+MODEL = os.path.join(ROOT, "tests", "golden", "models", "cfg2_d2_T128.pb")
+H, W = 1080, 1920
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+# ----------------------------------------------------------------------------- CPU baseline
+def _cpu_worker(seed):
+    import waldboost_amd as wb          # host-side .pb reader only; no GPU is touched here
+    from util import oracle_detect
+    from waldboost_amd.synth import synth_image
+    M = wb.load(MODEL)
+    t0 = time.perf_counter()
+    res = oracle_detect(M, synth_image(H, W, seed))
+    return res["n_loc"], time.perf_counter() - t0
+
+
+def cpu_baseline(images_per_core=1, max_cores=16):
+    import multiprocessing as mp
+    cores = max(1, min(max_cores, os.cpu_count() or 1))
+    n = cores * images_per_core
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        out = pool.map(_cpu_worker, range(n))
+    wall = time.perf_counter() - t0
+    windows = sum(o[0] for o in out)
+    return {"value": windows / wall, "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": f"{n} synthetic 1080p images, Pool({cores}) over images, NumPy oracle, {wall:.1f} s wall",
+            "single_core_windows_per_s": float(np.mean([o[0] / o[1] for o in out]))}
+
+
+# ----------------------------------------------------------------------------- helpers
+def event_time_ms(fn, iters, torch):
+    """Average duration of fn() over `iters` back-to-back launches, HIP events on the launch stream."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1, help="1080p images per step and GPU (configs[1] = 1, configs[2] = 64)")
+    ap.add_argument("--pool", type=int, default=4, help="distinct resident image batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--only", choices=["all", "channels", "cascade", "octaves"], default="all",
+                    help="profile helper: launch only one kernel group in the timed loop")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline and args.only == "all":
+        cpu = cpu_baseline()            # before the GPU is initialised (fork-safe)
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import waldboost_amd as wb
+    from waldboost_amd import _native as nat
+    from waldboost_amd.engine import PyramidEngine
+    from waldboost_amd.synth import synth_image
+    from waldboost_amd.distributed import DetectionGatherer
+
+    M = wb.load(MODEL)
+    dm = M.device_cascade()
+    B, P = args.batch, max(1, args.pool)
+    engines = []
+    for i in range(P):
+        e = PyramidEngine(H, W, np.uint8, 2, 8, 1, batch=B, det_capacity=max(1 << 15, 8192 * B))
+        seeds = [(rank * P + i) * B + b for b in range(B)]
+        e.load_images(np.stack([synth_image(H, W, s) for s in seeds]))
+        engines.append(e)
+    plan = engines[0].plan
+    n_loc = plan.n_loc(dm.m, dm.n)
+    torch.cuda.synchronize()
+
+    # ---- parity gate before timing: rank 0, engine 0, image 0 against the oracle
+    parity = None
+    if rank == 0 and args.only == "all":
+        from util import oracle_detect
+        e = engines[0]
+        stt = e.run(dm)
+        n_det = e.ensure_capacity(dm)
+        d = e.sorted_detections(n_det).cpu().numpy().view(nat.DET_DTYPE).reshape(-1)
+        d0 = d[d["image"] == 0]
+        alive0 = stt["alive"][0, :, :len(M)].cpu().numpy().astype(np.int64)
+        ref = oracle_detect(M, synth_image(H, W, (rank * P) * B))
+        ok = (np.array_equal(d0["level"], ref["level"]) and np.array_equal(d0["r"], ref["r"]) and
+              np.array_equal(d0["c"], ref["c"]) and np.array_equal(d0["score"].view(np.uint32), ref["scores"].view(np.uint32)) and
+              np.array_equal(alive0, ref["alive"]))
+        if not ok:
+            raise SystemExit("bench: GPU detections differ from the oracle -- refusing to time a wrong kernel")
+        parity = {"image": "seed 0", "detections": int(ref["scores"].size), "eval_cost": ref["n_weak"] / ref["n_loc"], "bit_exact": True}
+
+    # ---- step functions
+    if args.only == "all":
+        if args.no_graph:
+            steps = [(lambda e=e: e.run(dm)) for e in engines]
+        else:
+            graphs = [e.capture(dm) for e in engines]
+            steps = [g.replay for g in graphs]
+    elif args.only == "channels":
+        steps = [e.launch_channels for e in engines]
+    elif args.only == "octaves":
+        steps = [e.launch_octaves for e in engines]
+    else:
+        steps = [(lambda e=e: e.launch_cascade(dm)) for e in engines]
+
+    gath = comm = None
+    if world > 1:
+        gath = [DetectionGatherer(min(e.det_capacity, 4096 * B), e.dev) for e in engines]
+        comm = torch.cuda.Stream()
+        ev_done = [torch.cuda.Event() for _ in engines]      # step i's kernels finished
+        ev_comm = [torch.cuda.Event() for _ in engines]      # step i's gather finished
+
+    def run_steps(k0, k):
+        cur = torch.cuda.current_stream()
+        for i in range(k0, k0 + k):
+            j = i % P
+            if world > 1:
+                cur.wait_event(ev_comm[j])                   # buffer j free again
+            steps[j]()
+            if world > 1:
+                ev_done[j].record(cur)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ev_done[j])
+                    gath[j].gather(engines[j].det_buf)
+                    ev_comm[j].record(comm)
+        if world > 1:
+            cur.wait_stream(comm)
+
+    run_steps(0, args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.warmup, args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- per-kernel durations (HIP events, launch stream) and the roofline of the dominant one
+    roof = None
+    kern = {}
+    if rank == 0 and args.only == "all":
+        e = engines[0]
+        it = max(20, min(args.steps, 100))
+        kern["octaves_ms"] = event_time_ms(e.launch_octaves, it, torch)
+        kern["channels_ms"] = event_time_ms(e.launch_channels, it, torch)
+        kern["cascade_ms"] = event_time_ms(lambda: e.launch_cascade(dm), it, torch)
+        ab = plan.algorithmic_bytes(1)
+        name = "channels_kernel" if kern["channels_ms"] >= kern["cascade_ms"] else "cascade_kernel"
+        ms = kern["channels_ms"] if name == "channels_kernel" else kern["cascade_ms"]
+        abytes = ab[name] * B
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(f"{name}_b{B}")
+        roof = {"bound": "hbm", "kernel": name, "achieved": abytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": ms}
+
+    if rank == 0:
+        windows = world * args.steps * B * n_loc
+        ab = plan.algorithmic_bytes(1)
+        out = {
+            "metric": "candidate windows/s, 1080p grad_hist pyramid, 128-stage depth-2 cascade",
+            "value": windows / dt, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8 image, f64/f32 channel arithmetic, f32 scores", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: 1920x1080 uint8, shrink=2 n_per_oct=8 smooth=1 grad_hist, "
+                                   f"window (12,12,4), 128-stage depth-2 cascade, {B} image(s)/step/GPU",
+                       "batch_per_gpu": B, "levels": plan.n_levels, "windows_per_image": n_loc,
+                       "launch": "eager" if args.no_graph else "hipGraph replay", "only": args.only,
+                       "collective": "all_gather of detection prefix per step (side stream)" if world > 1 else "none"},
+            "mpixels_per_s": world * args.steps * B * H * W / dt / 1e6,
+            "images_per_s": world * args.steps * B / dt,
+            "pipeline_roofline_frac": (windows / dt) * (ab["total"] / n_loc) / (HBM_PEAK_GBS * 1e9 * world),
+            "kernels": kern, "parity": parity,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -125,8 +125,7 @@ class PyramidEngine:
         self.cs_sn = orientation_constants()
         self._oct_off = (C.c_int64 * max(p.n_oct, 1))(*[int(x) for x in p.oct_off[:max(p.n_oct, 1)]])
         self.det_capacity = int(det_capacity)
-        self.det = torch.empty((self.det_capacity, 4), dtype=torch.int32, device=dev)
-        self.det_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._alloc_det()
         self.alive = None
         self._casc = {}
         if exact_single:
@@ -137,6 +136,14 @@ class PyramidEngine:
                 lo, hi = 0, 255
             self.minmax[:, :, 0] = int(lo)
             self.minmax[:, :, 1] = int(hi)
+
+    def _alloc_det(self):
+        """Detection buffer: row 0 is a header whose first word is the survivor count, records
+        follow -- one contiguous block, so a fixed-size prefix can be handed to a collective."""
+        import torch
+        self.det_buf = torch.zeros((self.det_capacity + 1, 4), dtype=torch.int32, device=self.dev)
+        self.det_count = self.det_buf[0, 0:1]
+        self.det = self.det_buf[1:]
 
     # ------------------------------------------------------------------ input
     def load_images(self, images):
@@ -155,21 +162,28 @@ class PyramidEngine:
         self.img.copy_(t, non_blocking=True)
 
     # ------------------------------------------------------------------ launches
-    def run_channels(self):
+    def launch_octaves(self):
+        p = self.plan
+        if p.n_levels == 0 or self.exact_single:
+            return
+        nat.check(self.lib.wb_octaves_launch(nat.stream_ptr(), nat.ptr(self.img), self.wb_dtype, self.batch, p.H, p.W,
+                                             p.H * p.W, nat.ptr(self.oct), p.oct_total, self._oct_off, p.n_oct,
+                                             nat.ptr(self.minmax)), "wb_octaves_launch")
+
+    def launch_channels(self):
         p = self.plan
         if p.n_levels == 0:
             return
-        lib, st = self.lib, nat.stream_ptr()
-        if not self.exact_single:
-            nat.check(lib.wb_octaves_launch(st, nat.ptr(self.img), self.wb_dtype, self.batch, p.H, p.W,
-                                            p.H * p.W, nat.ptr(self.oct), p.oct_total, self._oct_off, p.n_oct,
-                                            nat.ptr(self.minmax)), "wb_octaves_launch")
-        nat.check(lib.wb_channels_launch(st, nat.ptr(self.img), p.H * p.W, nat.ptr(self.oct), p.oct_total,
-                                         self.wb_dtype, self.batch, nat.ptr(self.levels), p.n_levels,
-                                         nat.ptr(self.chan_tiles), self.n_chan_tiles, nat.ptr(self.minmax),
-                                         max(p.n_oct, 1), p.shrink, p.smooth,
-                                         self.cs_sn.ctypes.data_as(C.POINTER(C.c_double)), nat.ptr(self.chn),
-                                         self.chn_stride, self.layout), "wb_channels_launch")
+        nat.check(self.lib.wb_channels_launch(nat.stream_ptr(), nat.ptr(self.img), p.H * p.W, nat.ptr(self.oct),
+                                              p.oct_total, self.wb_dtype, self.batch, nat.ptr(self.levels),
+                                              p.n_levels, nat.ptr(self.chan_tiles), self.n_chan_tiles,
+                                              nat.ptr(self.minmax), max(p.n_oct, 1), p.shrink, p.smooth,
+                                              self.cs_sn.ctypes.data_as(C.POINTER(C.c_double)), nat.ptr(self.chn),
+                                              self.chn_stride, self.layout), "wb_channels_launch")
+
+    def run_channels(self):
+        self.launch_octaves()
+        self.launch_channels()
 
     def _casc_state(self, dm):
         import torch
@@ -185,11 +199,8 @@ class PyramidEngine:
             self._casc = {key: stt}          # one cascade resident per engine
         return stt
 
-    def run_cascade(self, dm):
-        """Zero the counters and scan every level of every image with cascade `dm`."""
+    def launch_cascade(self, dm):
         stt = self._casc_state(dm)
-        self.det_count.zero_()
-        stt["alive"].zero_()
         if stt["n_tiles"] == 0:
             return stt
         nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.chn), self.chn_stride,
@@ -198,6 +209,13 @@ class PyramidEngine:
                                              nat.ptr(self.det_count), self.det_capacity, nat.ptr(stt["alive"])),
                   "wb_cascade_launch")
         return stt
+
+    def run_cascade(self, dm):
+        """Zero the counters and scan every level of every image with cascade `dm`."""
+        stt = self._casc_state(dm)
+        self.det_count.zero_()
+        stt["alive"].zero_()
+        return self.launch_cascade(dm)
 
     def run(self, dm):
         self.run_channels()
@@ -227,7 +245,7 @@ class PyramidEngine:
         n = int(self.det_count.item()) & 0xFFFFFFFF
         while n > self.det_capacity:
             self.det_capacity = int(n * 1.25) + 1024
-            self.det = torch.empty((self.det_capacity, 4), dtype=torch.int32, device=self.dev)
+            self._alloc_det()
             self.run_cascade(dm)
             n = int(self.det_count.item()) & 0xFFFFFFFF
         return n
