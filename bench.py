@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="1080p images per step and GPU (configs[1] = 1, configs[2] = 64)")
     ap.add_argument("--pool", type=int, default=4, help="distinct resident image batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", type=int, default=0, help="diagnostic: keep only the first N stages of the cascade")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--only", choices=["all", "channels", "cascade", "octaves"], default="all",
                     help="profile helper: launch only one kernel group in the timed loop")
@@ -111,11 +112,13 @@ def main():
     from waldboost_amd.distributed import DetectionGatherer
 
     M = wb.load(MODEL)
+    if args.stages:
+        M.classifier, M.theta = M.classifier[:args.stages], M.theta[:args.stages]
     dm = M.device_cascade()
     B, P = args.batch, max(1, args.pool)
     engines = []
     for i in range(P):
-        e = PyramidEngine(H, W, np.uint8, 2, 8, 1, batch=B, det_capacity=max(1 << 15, 8192 * B))
+        e = PyramidEngine(H, W, np.uint8, 2, 8, 1, batch=B, det_capacity=16384 * B)
         seeds = [(rank * P + i) * B + b for b in range(B)]
         e.load_images(np.stack([synth_image(H, W, s) for s in seeds]))
         engines.append(e)
@@ -125,12 +128,12 @@ def main():
 
     # ---- parity gate before timing: rank 0, engine 0, image 0 against the oracle
     parity = None
-    if rank == 0 and args.only == "all":
+    if rank == 0 and args.only == "all" and not args.stages:
         from util import oracle_detect
         e = engines[0]
         stt = e.run(dm)
         n_det = e.ensure_capacity(dm)
-        d = e.sorted_detections(n_det).cpu().numpy().view(nat.DET_DTYPE).reshape(-1)
+        d = e.sorted_detections().cpu().numpy().view(nat.DET_DTYPE).reshape(-1)
         d0 = d[d["image"] == 0]
         alive0 = stt["alive"][0, :, :len(M)].cpu().numpy().astype(np.int64)
         ref = oracle_detect(M, synth_image(H, W, (rank * P) * B))
@@ -153,11 +156,11 @@ def main():
     elif args.only == "octaves":
         steps = [e.launch_octaves for e in engines]
     else:
-        steps = [(lambda e=e: e.launch_cascade(dm)) for e in engines]
+        steps = [(lambda e=e: e.run_cascade(dm)) for e in engines]
 
     gath = comm = None
     if world > 1:
-        gath = [DetectionGatherer(min(e.det_capacity, 4096 * B), e.dev) for e in engines]
+        gath = [DetectionGatherer(e.detb) for e in engines]
         comm = torch.cuda.Stream()
         ev_done = [torch.cuda.Event() for _ in engines]      # step i's kernels finished
         ev_comm = [torch.cuda.Event() for _ in engines]      # step i's gather finished
@@ -173,7 +176,7 @@ def main():
                 ev_done[j].record(cur)
                 with torch.cuda.stream(comm):
                     comm.wait_event(ev_done[j])
-                    gath[j].gather(engines[j].det_buf)
+                    gath[j].gather(engines[j].detb)
                     ev_comm[j].record(comm)
         if world > 1:
             cur.wait_stream(comm)
@@ -203,7 +206,7 @@ def main():
         it = max(20, min(args.steps, 100))
         kern["octaves_ms"] = event_time_ms(e.launch_octaves, it, torch)
         kern["channels_ms"] = event_time_ms(e.launch_channels, it, torch)
-        kern["cascade_ms"] = event_time_ms(lambda: e.launch_cascade(dm), it, torch)
+        kern["cascade_ms"] = event_time_ms(lambda: e.run_cascade(dm), it, torch)   # tile + deep kernels (+ counter resets)
         ab = plan.algorithmic_bytes(1)
         name = "channels_kernel" if kern["channels_ms"] >= kern["cascade_ms"] else "cascade_kernel"
         ms = kern["channels_ms"] if name == "channels_kernel" else kern["cascade_ms"]

@@ -50,6 +50,12 @@ extern "C" {
 
 #define WB_MAX_OCTAVES 24
 
+/* Detection / work-queue buffers are split into WB_DET_SHARDS independent append regions, each
+ * with its own counter, so that concurrent workgroups do not serialise on one atomic word:
+ *   records of shard s : det[s*shard_capacity .. s*shard_capacity + min(count[s], shard_capacity))
+ * A workgroup appends to shard (blockIdx.x % WB_DET_SHARDS). */
+#define WB_DET_SHARDS 64
+
 /* One pyramid level (reference channels.py:127-146).  Built on the host: the level
  * plan is Python-float arithmetic in the reference and stays there. */
 typedef struct WbLevel {
@@ -94,6 +100,8 @@ typedef struct WbModelInfo {
     int32_t tile_rows;  /* cascade tile: tile_rows x 64 windows per workgroup      */
     int32_t tile_cols;
     int32_t lds_bytes;  /* dynamic LDS per workgroup of the cascade kernel         */
+    int32_t handoff_stage; /* stages [0, handoff) run in the tile kernel, the rest in the
+                              deep kernel; == n_stages when the cascade is not split    */
 } WbModelInfo;
 
 int wb_abi_version(void);
@@ -144,15 +152,21 @@ int wb_model_info(const WbModel *model, WbModelInfo *info);
  *   chn/layout    as written by wb_channels_launch (or caller-provided HWC arrays)
  *   tiles         dev WbTile[n_tiles]: tiles of tile_rows x tile_cols WINDOWS over the
  *                 (u-m) x (v-n) window grid of each level
- *   det           dev WbDet[capacity]; det_count dev uint32: number of survivors (may
- *                 exceed capacity: records beyond capacity are dropped, count is exact)
+ *   det           dev WbDet[WB_DET_SHARDS][shard_capacity]; det_count dev uint32[WB_DET_SHARDS]:
+ *                 survivors per shard (a count may exceed shard_capacity: the records beyond it
+ *                 are dropped, the count stays exact -- grow the buffer and launch again)
+ *   work          dev WbDet[WB_DET_SHARDS][shard_capacity] + work_count uint32[WB_DET_SHARDS]:
+ *                 queue between the tile kernel (first stages, LDS-tiled) and the deep kernel
+ *                 (remaining stages, one wavefront per surviving window); only used by cascades
+ *                 long enough to be split (WbModelInfo.handoff_stage < n_stages), may be NULL
+ *                 otherwise.  An overflowing work shard loses windows: check work_count too.
  *   alive         dev uint32 [batch][n_levels][n_stages]: windows entering each stage
- * det_count and alive are ACCUMULATED into: the caller zeroes them. Record order is
- * unspecified; sort by (image, level, r, c) to obtain the reference order. */
+ * det_count, work_count and alive are ACCUMULATED into: the caller zeroes them.  Record order
+ * is unspecified; sort by (image, level, r, c) to obtain the reference order. */
 int wb_cascade_launch(void *stream, const WbModel *model, const float *chn, int64_t chn_stride,
                       int layout, int batch, const WbLevel *levels, int n_levels,
                       const WbTile *tiles, int n_tiles, WbDet *det, uint32_t *det_count,
-                      uint32_t capacity, uint32_t *alive);
+                      uint32_t shard_capacity, WbDet *work, uint32_t *work_count, uint32_t *alive);
 
 /* One tree evaluated at explicit window origins (rs[i], cs[i]) of an HWC channel image
  * X[u][v][C]; out[i] = prediction of the leaf reached (training.py:84-96). Tree arrays

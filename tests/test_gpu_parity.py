@@ -224,3 +224,56 @@ def test_1080p_depth2_128_stages_vs_oracle():
     assert ref["n_loc"] == 3045278 == M.n_loc
     assert_same_detections(res, ref)
     assert M.n_weak == ref["n_weak"]
+
+
+# ------------------------------------------------------------------------------ octaves
+@pytest.mark.parametrize("shape,dtype", [((1080, 1920), np.float32), ((2160, 3840), np.uint8), ((1081, 1923), np.uint8),
+                                         ((8, 8), np.uint8), ((517, 263), np.float32)])
+def test_octaves_and_clip_range_vs_oracle(shape, dtype):
+    """The fused octave kernel (block kernel + tail kernel for deep pyramids) against the
+    oracle's avg_pool_2 chain, including the uint8 wrap and the per-octave min/max."""
+    from waldboost_amd.engine import PyramidEngine
+    img = synth_image(shape[0], shape[1], 17, dtype)
+    if dtype == np.uint8:
+        img = np.clip(img.astype(np.int32) + 70, 0, 255).astype(np.uint8)
+    e = PyramidEngine(shape[0], shape[1], dtype, 2, 8, 1, batch=1)
+    e.load_images(img)
+    e.launch_octaves()
+    octs = list(orc.image_octaves(img))
+    assert len(octs) == e.plan.n_oct
+    buf = e.oct[0].cpu().numpy()
+    mm = e.minmax[0].cpu().numpy().view(np.uint32)
+    for k, o in enumerate(octs):
+        if k:
+            got = buf[int(e.plan.oct_off[k]):int(e.plan.oct_off[k]) + o.size].reshape(o.shape)
+            assert np.array_equal(got.view(np.uint8), o.view(np.uint8)), k
+        lo_key, hi_key = np.uint32(~mm[k, 0]), mm[k, 1]
+        if dtype == np.uint8:
+            assert (int(lo_key), int(hi_key)) == (int(o.min()), int(o.max())), k
+        else:
+            from waldboost_amd.engine import nat_f32_key
+            assert lo_key == nat_f32_key(o.min()) and hi_key == nat_f32_key(o.max()), k
+
+
+# ------------------------------------------------------------------------------ split cascade
+@pytest.mark.parametrize("depth,T,handoff", [(2, 70, None), (1, 100, None), (3, 66, None), (2, 50, "8"), (2, 130, "64"),
+                                             (2, 90, "0")])
+def test_long_cascades_split_between_tile_and_deep_kernel(depth, T, handoff, monkeypatch):
+    """Cascades longer than handoff+16 stages finish in the stage-parallel deep kernel; the
+    hand-off stage must not change any result (WB_CASC_HANDOFF=8 floods the work queue and
+    forces the buffers to grow, =0 disables the split)."""
+    if handoff is not None:
+        monkeypatch.setenv("WB_CASC_HANDOFF", handoff)
+    img = synth_image(260, 380, 50 + T)
+    M = random_model(300 + T, T, depth)
+    # mild thresholds (a slowly falling floor) so that a fair share of windows reaches the late stages
+    M.theta = [float(np.float32(-1.0 - 0.3 * i)) if i % 3 == 0 else float("-inf") for i in range(T)]
+    M._device = None
+    dm = M.device_cascade()
+    expect = T if handoff == "0" else (int(handoff) if handoff else 32)
+    assert dm.handoff_stage == (expect if T > expect + 16 else T)
+    res = M.detect_raw(img)
+    ref = oracle_detect(M, img)
+    assert ref["alive"][:, -1].sum() > 0
+    assert_same_detections(res, ref)
+    assert M.n_weak == ref["n_weak"]

@@ -1,13 +1,15 @@
 // C-ABI glue: error reporting and the cascade model handle (host-side canonicalisation of the
 // reference's flat-array decision trees into the complete-tree stage records the kernels read).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
 
 #include "wb_common.h"
 
-int wb_cascade_prepare(int depth, int rpw);  // wb_cascade.hip
+int wb_cascade_prepare(int depth, int rpw, int waves);  // wb_cascade.hip
+int wb_cascade_group(int depth);                        // stages evaluated per group
 
 static thread_local char g_err[512] = "";
 
@@ -109,14 +111,18 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
     M->n = n;
     M->C = C;
     M->lds_pitch = ((WB_CASC_TC + n - 1) + 3) & ~3;
+    // tile = (rpw * waves) x 64 windows; WB_CASC_RPW / WB_CASC_WAVES override the default for tuning
     const int budget = 80 * 1024;
-    int rpw = 8;
+    int rpw = 4, waves = 8;
+    if (const char *e = getenv("WB_CASC_RPW")) rpw = atoi(e);
+    if (const char *e = getenv("WB_CASC_WAVES")) waves = atoi(e);
     for (;; rpw >>= 1) {
         M->rpw = rpw;
-        M->tile_rows = rpw * WB_CASC_WAVES;
+        M->waves = waves;
+        M->tile_rows = rpw * waves;
         M->lds_rows = M->tile_rows + m - 1;
         M->lds_bytes = C * M->lds_rows * M->lds_pitch * 4 + M->tile_rows * WB_CASC_TC * 8 + n_stages * 4;
-        if (M->lds_bytes <= budget || rpw == 1) break;
+        if (M->lds_bytes <= budget || rpw <= 1) break;
     }
     if (M->lds_bytes > 160 * 1024) {
         wb_set_error("wb_model_create: window (%d,%d,%d) with %d stages needs %d B of LDS (> 160 KiB)", m, n, C,
@@ -125,10 +131,18 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         return WB_ERR_UNSUPPORTED;
     }
     M->stage_dwords = WB_STAGE_DWORDS(D);
+    // long cascades are split: the LDS-tiled kernel runs the first `handoff` stages, the few
+    // windows that survive them finish in the deep kernel (WB_CASC_HANDOFF overrides, 0 = never)
+    int handoff = 32;
+    if (const char *e = getenv("WB_CASC_HANDOFF")) handoff = atoi(e) & ~3;
+    M->t_tile = (handoff > 0 && n_stages > handoff + 16) ? handoff : n_stages;
 
     // ---- pack and upload the stage records
     const int NI = (1 << D) - 1, NL = 1 << D, SD = M->stage_dwords;
-    std::vector<int32_t> packed((size_t)n_stages * SD, 0);
+    // G trailing no-op records (offset 0, prediction 0, theta -inf) so a group load never leaves the table
+    const int G = wb_cascade_group(D);
+    std::vector<int32_t> packed((size_t)(n_stages + G) * SD, 0);
+    for (int s = n_stages; s < n_stages + G; ++s) reinterpret_cast<float *>(packed.data() + (size_t)s * SD)[2 * NI + NL] = -INFINITY;
     for (int s = 0; s < n_stages; ++s) {
         int32_t *rec = packed.data() + (size_t)s * SD;
         int32_t *off = rec;
@@ -137,19 +151,35 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         fill(trees[s], 0, 0, 0, D, M->lds_rows, M->lds_pitch, off, thr, pred);
         reinterpret_cast<float *>(rec)[2 * NI + NL] = theta[s];
     }
-    if (n_stages > 0) {
+    // the same records with features as packed (row | col<<8 | channel<<16): the deep kernel
+    // gathers from the level's own planes in HBM, whose pitch is not known here
+    std::vector<int32_t> packed_feat((size_t)(n_stages + 1) * SD, 0);
+    for (int s = 0; s < n_stages; ++s) {
+        int32_t *rec = packed_feat.data() + (size_t)s * SD;
+        memcpy(rec, packed.data() + (size_t)s * SD, (size_t)SD * 4);
+        for (int i = 0; i < NI; ++i) {
+            int o = packed[(size_t)s * SD + i];
+            int ch = o / (M->lds_rows * M->lds_pitch), rem = o % (M->lds_rows * M->lds_pitch);
+            rec[i] = (rem / M->lds_pitch) | ((rem % M->lds_pitch) << 8) | (ch << 16);
+        }
+    }
+    {
         hipError_t e = hipMalloc((void **)&M->stages_dev, packed.size() * 4);
         if (e == hipSuccess) e = hipMemcpy(M->stages_dev, packed.data(), packed.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void **)&M->stages_feat_dev, packed_feat.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(M->stages_feat_dev, packed_feat.data(), packed_feat.size() * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             wb_set_error("wb_model_create: uploading %zu stage bytes failed: %s", packed.size() * 4, hipGetErrorString(e));
             if (M->stages_dev) (void)hipFree(M->stages_dev);
+            if (M->stages_feat_dev) (void)hipFree(M->stages_feat_dev);
             delete M;
             return WB_ERR_HIP;
         }
     }
-    int rc = wb_cascade_prepare(D, M->rpw);
+    int rc = wb_cascade_prepare(D, M->rpw, M->waves);
     if (rc != WB_OK) {
         if (M->stages_dev) (void)hipFree(M->stages_dev);
+        if (M->stages_feat_dev) (void)hipFree(M->stages_feat_dev);
         delete M;
         return rc;
     }
@@ -160,6 +190,7 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
 extern "C" int wb_model_destroy(WbModel *model) {
     if (!model) return WB_OK;
     if (model->stages_dev) (void)hipFree(model->stages_dev);
+    if (model->stages_feat_dev) (void)hipFree(model->stages_feat_dev);
     delete model;
     return WB_OK;
 }
@@ -174,5 +205,6 @@ extern "C" int wb_model_info(const WbModel *model, WbModelInfo *info) {
     info->tile_rows = model->tile_rows;
     info->tile_cols = WB_CASC_TC;
     info->lds_bytes = model->lds_bytes;
+    info->handoff_stage = model->t_tile;
     return WB_OK;
 }

@@ -4,18 +4,30 @@
 // rejection, compaction, n_loc/n_weak statistics) and training.py:84-96
 // (DTree.predict_on_image: the tree walk on all alive windows).
 //
-// One workgroup (4 wavefronts) owns a tile of TR x 64 windows of one level of one image:
+// Two kernels:
+//
+// tile kernel  -- stages [0, S_h).  One workgroup owns a tile of TR x 64 windows of one level of
+//   one image:
 //   * the (TR+m-1) x (64+n-1) x C channel block is staged once into LDS, planar, so that a
 //     wavefront's 64 lanes (64 adjacent window columns) gather from 64 adjacent banks;
 //   * the stage loop is wave-synchronous: every lane of a wave is at the same stage, so the
-//     stage record (feature offsets, thresholds, leaf values, theta) comes in through the
-//     scalar cache (s_load) and costs no vector memory or LDS traffic;
-//   * phase A runs the first stages with RPW windows per lane (ILP hides the LDS latency);
-//     survivors are compacted with wave ballot + mbcnt into the wave's own LDS queue;
-//   * phase B re-packs the survivors densely (64 per wave-iteration) for geometrically
-//     growing stage segments, compacting in place after each segment;
-//   * windows alive after the last stage are appended to the detection buffer with one
-//     wave-aggregated global atomic; per-stage alive counts go through an LDS histogram.
+//     stage records come in through the scalar cache (s_load) and cost no vector memory or LDS
+//     traffic; stages are evaluated in groups of G with all 2*G gathers in flight (only the
+//     fp32 accumulation and the rejection tests are sequential);
+//   * phase A runs the first stages with RPW windows per lane; survivors are compacted with
+//     wave ballot + mbcnt into the wave's own LDS queue; phase B re-packs them densely for
+//     geometrically growing stage segments, compacting in place after each segment;
+//   * the windows still alive after stage S_h-1 stay in the wave's queue; one thread then
+//     reserves room for the whole workgroup with ONE atomic on one of WB_DET_SHARDS counters
+//     and the waves copy their records out.
+//
+// deep kernel  -- stages [S_h, T), only when the cascade is much longer than S_h.
+//   Few windows get this far (about 1e-3 for the benchmark cascade) but they have ~100 stages
+//   to go; kept in the tile kernel they would pin a workgroup's LDS tile for the whole serial
+//   walk.  Here one wavefront takes one survivor and evaluates 64 stages AT ONCE, one stage per
+//   lane (stage records and feature gathers straight from HBM/L2), then replays the fp32
+//   accumulation and the rejection tests serially in stage order with v_readlane -- the same
+//   additions in the same order as the reference, so scores stay bit-identical.
 //
 // Scores are accumulated in fp32 strictly in stage order and compared with `>=`, so they are
 // bit-identical to the reference's `hs += ...; mask = hs >= theta`.
@@ -30,12 +42,17 @@ struct CascArgs {
     const WbLevel *levels;
     const WbTile *tiles;
     int n_levels;
-    const int32_t *stages;
+    const int32_t *stages;      // LDS-offset records (tile kernel)
+    const int32_t *stages_feat; // packed (row, col, channel) records (deep kernel)
     int T, m, n, C;
+    int t_tile;                 // stages run by the tile kernel (S_h, or T when there is no deep kernel)
     int lds_rows, lds_pitch;
-    WbDet *det;
+    WbDet *out;                 // where the tile kernel appends: work queue or detections
+    uint32_t *out_count;
+    uint32_t out_cap;           // per shard
+    WbDet *det;                 // deep kernel output
     uint32_t *det_count;
-    uint32_t capacity;
+    uint32_t det_cap;           // per shard
     uint32_t *alive;
 };
 
@@ -53,7 +70,8 @@ template <typename V> struct Sel<1, V> {
     static __device__ inline V get(const V *a, int) { return a[0]; }
 };
 
-// The stage record, pulled into SGPRs by the caller (wave-uniform address).
+// The stage record (see wb_common.h), pulled into SGPRs by the tile kernel (wave-uniform
+// address).
 template <int D> struct Stage {
     static constexpr int NI = WB_STAGE_NI(D), NL = WB_STAGE_NL(D);
     int off[NI];
@@ -89,18 +107,31 @@ __device__ inline int lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
-template <int D, int RPW>
-__global__ __launch_bounds__(256) void cascade_kernel(CascArgs a, const int32_t *__restrict__ stages) {
+// Stages are evaluated in groups of G: the G tree walks of a window are independent (only the
+// fp32 accumulation and the rejection tests are sequential), so their 2*G LDS gathers and the G
+// scalar record loads are all in flight together and the wave's latency chain per stage drops
+// G-fold.  A window that dies inside a group has had a few stages evaluated in vain; nothing it
+// produced is ever used.  The stage table is padded with G no-op records so a group may start
+// at any stage < T.
+template <int D> struct GroupSize { static constexpr int G = (D >= 3) ? 2 : 4; };
+
+template <int D, int RPW, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, const int32_t *__restrict__ stages) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TR = RPW * WB_CASC_WAVES;
+    __shared__ uint32_t wcnt[WAVES];
+    __shared__ uint32_t wg_base;
+    constexpr int NT = WAVES * 64;
+    constexpr int TR = RPW * WAVES;
     constexpr int SD = WB_STAGE_DWORDS(D);
-    constexpr int S0 = 4;                                  // stages in phase A
+    constexpr int G = GroupSize<D>::G;
+    constexpr int S0 = 4;                                  // stages in phase A (multiple of G)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const WbTile tile_d = a.tiles[blockIdx.x];
     const WbLevel L = a.levels[tile_d.level];
     const int b = blockIdx.y;
     const int pitch = a.lds_pitch, rows = a.lds_rows;
+    const int T = a.t_tile;
 
     float *tile = reinterpret_cast<float *>(smem);
     const int tile_floats = a.C * rows * pitch;
@@ -111,32 +142,43 @@ __global__ __launch_bounds__(256) void cascade_kernel(CascArgs a, const int32_t 
     const int nc = L.v - a.n > 0 ? L.v - a.n : 0;
     const int r0 = tile_d.ty * TR, c0 = tile_d.tx * WB_CASC_TC;
 
-    for (int t = tid; t < a.T; t += 256) hist[t] = 0;
+    for (int t = tid; t < T; t += NT) hist[t] = 0;
 
     // ---- stage the channel block into LDS (planar [C][rows][pitch])
     const float *chn = a.chn + (int64_t)b * a.chn_stride + L.chn_off;
     if (a.layout == WB_LAYOUT_PLANAR) {
+        // The LDS tile is one linear array of float4 (pitch is a multiple of 4), element e =
+        // (ch*rows + row)*p4 + q.  Each thread owns elements tid, tid+NT, ...; U of them are
+        // loaded back to back before the first LDS store so that U HBM/L2 requests per lane are
+        // in flight (a load-store-load-store loop serialises on memory latency).
+        constexpr int U = 8;
         const int p4 = pitch >> 2;
-        const int per_ch = rows * p4;
+        const int total4 = a.C * rows * p4;
         const int64_t plane = (int64_t)L.u * L.vp;
-        for (int ch = 0; ch < a.C; ++ch) {
-            const float *src = chn + ch * plane;
-            float *dst = tile + ch * rows * pitch;
-            int row = tid / p4, q = tid - row * p4;
-            const int drow = 256 / p4, dq = 256 - drow * p4;
-            for (int idx = tid; idx < per_ch; idx += 256) {
+        const int drow = NT / p4, dq = NT - drow * p4;
+        int rowall = tid / p4, q = tid - rowall * p4;       // rowall = ch*rows + row
+        int ch = rowall / rows, row = rowall - ch * rows;
+        float4 *tile4 = reinterpret_cast<float4 *>(tile);
+        for (int e0 = tid; e0 < total4; e0 += NT * U) {
+            float4 v[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 int gr = r0 + row, gc = c0 + 4 * q;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gr < L.u && gc < L.vp) v = *reinterpret_cast<const float4 *>(src + (int64_t)gr * L.vp + gc);
-                *reinterpret_cast<float4 *>(dst + row * pitch + 4 * q) = v;
+                if (e0 + k * NT < total4 && gr < L.u && gc < L.vp)
+                    v[k] = *reinterpret_cast<const float4 *>(chn + ch * plane + (int64_t)gr * L.vp + gc);
                 row += drow;
                 q += dq;
                 if (q >= p4) { q -= p4; ++row; }
+                while (row >= rows) { row -= rows; ++ch; }
             }
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+                if (e0 + k * NT < total4) tile4[e0 + k * NT] = v[k];
         }
     } else {  // HWC arrays handed in by a caller (Model.predict_on_image on host data)
         const int total = a.C * rows * pitch;
-        for (int idx = tid; idx < total; idx += 256) {
+        for (int idx = tid; idx < total; idx += NT) {
             int ch = idx % a.C;
             int rc = idx / a.C;
             int col = rc % pitch, row = rc / pitch;
@@ -159,58 +201,50 @@ __global__ __launch_bounds__(256) void cascade_kernel(CascArgs a, const int32_t 
         live[j] = (c0 + lane < nc) && (r0 + wr + j < nr);
         base[j] = (wr + j) * pitch + lane;
     }
-    const int tA = a.T < S0 ? a.T : S0;
-    for (int t = 0; t < tA; ++t) {
-        int cnt = 0;
+    const int tA = T < S0 ? T : S0;
+    for (int t = 0; t < tA; t += G) {
+        Stage<D> st[G];
+        const int32_t *sp = stages + (size_t)__builtin_amdgcn_readfirstlane(t) * SD;
 #pragma unroll
-        for (int j = 0; j < RPW; ++j) cnt += __popcll(__ballot(live[j]));
-        if (cnt == 0) break;
-        if (lane == 0) atomicAdd(&hist[t], (uint32_t)cnt);
-        Stage<D> st;
-        st.load(stages + (size_t)__builtin_amdgcn_readfirstlane(t) * SD);
-        const bool rejects = st.theta != -INFINITY;
+        for (int g = 0; g < G; ++g) st[g].load(sp + g * SD);
+        float p[G][RPW];
 #pragma unroll
-        for (int j = 0; j < RPW; ++j) {
-            float p = st.eval(tile, base[j]);
-            float h = hs[j] + p;
-            hs[j] = live[j] ? h : hs[j];
-            live[j] = live[j] && (!rejects || h >= st.theta);
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) p[g][j] = st[g].eval(tile, base[j]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (t + g >= tA) break;
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) cnt += __popcll(__ballot(live[j]));
+            if (cnt && lane == 0) atomicAdd(&hist[t + g], (uint32_t)cnt);
+            const bool rejects = st[g].theta != -INFINITY;
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                float h = hs[j] + p[g][j];
+                hs[j] = live[j] ? h : hs[j];
+                live[j] = live[j] && (!rejects || h >= st[g].theta);
+            }
         }
     }
 
-    // survivors of phase A -> this wave's queue (or straight out when the model is short)
+    // survivors of phase A -> this wave's queue
     int n_q = 0;
-    const bool last_seg_A = (tA >= a.T);
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         unsigned long long mask = __ballot(live[j]);
         int cnt = __popcll(mask);
         if (cnt == 0) continue;
         int rank = lane_rank(mask);
-        if (last_seg_A) {
-            uint32_t gbase = 0;
-            if (lane == 0) gbase = atomicAdd(a.det_count, (uint32_t)cnt);
-            gbase = __builtin_amdgcn_readfirstlane(gbase);
-            if (live[j] && gbase + rank < a.capacity) {
-                WbDet d;
-                d.image = b;
-                d.level = tile_d.level;
-                d.r = (uint16_t)(r0 + wr + j);
-                d.c = (uint16_t)(c0 + lane);
-                d.score = hs[j];
-                a.det[gbase + rank] = d;
-            }
-        } else if (live[j]) {
-            queue[n_q + rank] = make_uint2((uint32_t)((wr + j) * 64 + lane), __float_as_uint(hs[j]));
-        }
+        if (live[j]) queue[n_q + rank] = make_uint2((uint32_t)((wr + j) * 64 + lane), __float_as_uint(hs[j]));
         n_q += cnt;
     }
 
     // ---- phase B: dense re-packed survivors, stage segments [S0,2S0), [2S0,4S0), ...
     int t_begin = tA;
-    while (t_begin < a.T && n_q > 0) {
-        int t_end = 2 * t_begin < a.T ? 2 * t_begin : a.T;
-        const bool last = (t_end == a.T);
+    while (t_begin < T && n_q > 0) {
+        int t_end = 2 * t_begin < T ? 2 * t_begin : T;
         int n_out = 0;
         for (int qb = 0; qb < n_q; qb += 64) {
             int i = qb + lane;
@@ -219,51 +253,164 @@ __global__ __launch_bounds__(256) void cascade_kernel(CascArgs a, const int32_t 
             int pos = (int)e.x;
             float h = __uint_as_float(e.y);
             int wbase = (pos >> 6) * pitch + (pos & 63);
-            for (int t = t_begin; t < t_end; ++t) {
-                int cnt = __popcll(__ballot(alive));
-                if (cnt == 0) break;
-                if (lane == 0) atomicAdd(&hist[t], (uint32_t)cnt);
-                Stage<D> st;
-                st.load(stages + (size_t)__builtin_amdgcn_readfirstlane(t) * SD);
-                float p = st.eval(tile, wbase);
-                float h2 = h + p;
-                h = alive ? h2 : h;
-                alive = alive && (st.theta == -INFINITY || h2 >= st.theta);
+            for (int t = t_begin; t < t_end; t += G) {
+                if (__ballot(alive) == 0ull) break;
+                Stage<D> st[G];
+                const int32_t *sp = stages + (size_t)__builtin_amdgcn_readfirstlane(t) * SD;
+#pragma unroll
+                for (int g = 0; g < G; ++g) st[g].load(sp + g * SD);
+                float p[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) p[g] = st[g].eval(tile, wbase);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (t + g >= t_end) break;
+                    int cnt = __popcll(__ballot(alive));
+                    if (cnt && lane == 0) atomicAdd(&hist[t + g], (uint32_t)cnt);
+                    float h2 = h + p[g];
+                    h = alive ? h2 : h;
+                    alive = alive && (st[g].theta == -INFINITY || h2 >= st[g].theta);
+                }
             }
             unsigned long long mask = __ballot(alive);
             int cnt = __popcll(mask);
             if (cnt) {
-                int rank = lane_rank(mask);
-                if (last) {
-                    uint32_t gbase = 0;
-                    if (lane == 0) gbase = atomicAdd(a.det_count, (uint32_t)cnt);
-                    gbase = __builtin_amdgcn_readfirstlane(gbase);
-                    if (alive && gbase + rank < a.capacity) {
-                        WbDet d;
-                        d.image = b;
-                        d.level = tile_d.level;
-                        d.r = (uint16_t)(r0 + (pos >> 6));
-                        d.c = (uint16_t)(c0 + (pos & 63));
-                        d.score = h;
-                        a.det[gbase + rank] = d;
-                    }
-                } else if (alive) {
-                    // in place: n_out + rank <= qb + lane, and this wave already holds chunk qb in registers
-                    queue[n_out + rank] = make_uint2((uint32_t)pos, __float_as_uint(h));
-                }
+                // in place: n_out + rank <= qb + lane, and this wave already holds chunk qb in registers
+                if (alive) queue[n_out + lane_rank(mask)] = make_uint2((uint32_t)pos, __float_as_uint(h));
                 n_out += cnt;
             }
         }
         n_q = n_out;
         t_begin = t_end;
     }
+    if (t_begin < T) n_q = 0;   // every window of this wave died before the last tile-kernel stage
 
-    // ---- per-stage alive counts of this tile -> global statistics
+    // ---- epilogue: the wave queues now hold the windows alive after stage T-1.  One atomic per
+    //      workgroup reserves their slots in one of the sharded output buffers.
+    if (lane == 0) wcnt[wave] = (uint32_t)n_q;
     __syncthreads();
+    const uint32_t shard = blockIdx.x % WB_DET_SHARDS;
+    if (tid == 0) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) total += wcnt[w];
+        wg_base = total ? atomicAdd(a.out_count + shard, total) : 0u;
+    }
     uint32_t *al = a.alive + ((int64_t)b * a.n_levels + tile_d.level) * a.T;
-    for (int t = tid; t < a.T; t += 256) {
+    for (int t = tid; t < T; t += NT) {
         uint32_t v = hist[t];
         if (v) atomicAdd(al + t, v);
+    }
+    __syncthreads();
+    if (n_q > 0) {
+        uint32_t o = wg_base;
+        for (int w = 0; w < wave; ++w) o += wcnt[w];
+        WbDet *dst = a.out + (size_t)shard * a.out_cap;
+        for (int i = lane; i < n_q; i += 64) {
+            uint2 e = queue[i];
+            if (o + i < a.out_cap) {
+                WbDet d;
+                d.image = b;
+                d.level = tile_d.level;
+                d.r = (uint16_t)(r0 + ((int)e.x >> 6));
+                d.c = (uint16_t)(c0 + ((int)e.x & 63));
+                d.score = __uint_as_float(e.y);
+                dst[o + i] = d;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// deep kernel: one wavefront per surviving window, one stage per lane, 64 stages per round.
+// grid = WB_DET_SHARDS * K workgroups of 4 waves; workgroup (s, k) walks entries of shard s.
+template <int D>
+__global__ __launch_bounds__(256) void cascade_deep_kernel(CascArgs a) {
+    constexpr int NI = WB_STAGE_NI(D), NL = WB_STAGE_NL(D), SD = WB_STAGE_DWORDS(D);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t shard = blockIdx.x % WB_DET_SHARDS;
+    const uint32_t k = blockIdx.x / WB_DET_SHARDS, K = gridDim.x / WB_DET_SHARDS;
+    uint32_t n_in = a.out_count[shard];
+    if (n_in > a.out_cap) n_in = a.out_cap;
+    const WbDet *src = a.out + (size_t)shard * a.out_cap;
+    const int T = a.T, t0 = a.t_tile;
+
+    for (uint32_t ei = k * 4 + wave; ei < n_in; ei += K * 4) {
+        const WbDet d = src[ei];                               // same address in every lane
+        const int level = __builtin_amdgcn_readfirstlane(d.level);
+        const int image = __builtin_amdgcn_readfirstlane(d.image);
+        const WbLevel L = a.levels[level];
+        const float *chn = a.chn + (int64_t)image * a.chn_stride + L.chn_off;
+        const int r = d.r, c = d.c;
+        float h = d.score;
+        bool dead = false;
+        uint32_t *al = a.alive + ((int64_t)image * a.n_levels + level) * T;
+
+        for (int rs = t0; rs < T && !dead; rs += 64) {
+            const int t = rs + lane;
+            const int nvalid = T - rs < 64 ? T - rs : 64;
+            // this lane's stage (lanes past T re-read the last record; their result is never used)
+            const int32_t *sp = a.stages_feat + (size_t)(t < T ? t : T - 1) * SD;
+            int feat[NI];
+            float thr[NI], pred[NL];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) feat[i] = sp[i];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) thr[i] = as_f(sp[NI + i]);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) pred[i] = as_f(sp[2 * NI + i]);
+            float theta = as_f(sp[2 * NI + NL]);
+
+            int path = 0;
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) {
+                const int first = (1 << dd) - 1;
+                int f = feat[first];
+                float th = thr[first];
+#pragma unroll
+                for (int q = 1; q < (1 << dd); ++q) {          // per-lane select of the node on the path
+                    bool take = (path == q);
+                    f = take ? feat[first + q] : f;
+                    th = take ? thr[first + q] : th;
+                }
+                int fr = f & 255, fc = (f >> 8) & 255, ch = (f >> 16) & 255;
+                float v;
+                if (a.layout == WB_LAYOUT_PLANAR)
+                    v = chn[(int64_t)ch * L.u * L.vp + (int64_t)(r + fr) * L.vp + (c + fc)];
+                else
+                    v = chn[((int64_t)(r + fr) * L.v + (c + fc)) * a.C + ch];
+                path = 2 * path + ((v <= th) ? 0 : 1);
+            }
+            float p = pred[0];
+#pragma unroll
+            for (int q = 1; q < NL; ++q) p = (path == q) ? pred[q] : p;
+
+            // serial replay in stage order: h += p_t ; reject if theta_t != -inf and !(h >= theta_t)
+            int last = nvalid - 1;                                // last stage this window enters
+            for (int i = 0; i < nvalid; ++i) {                   // every lane computes the same h
+                float pi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), i));
+                float ti = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(theta), i));
+                h = h + pi;
+                int rej = (ti != -INFINITY && !(h >= ti)) ? 1 : 0;
+                if (__builtin_amdgcn_readfirstlane(rej)) {
+                    dead = true;
+                    last = i;
+                    break;
+                }
+            }
+            if (lane <= last) atomicAdd(al + t, 1u);              // windows entering stage t
+        }
+
+        if (!dead) {
+            uint32_t slot = 0;
+            if (lane == 0) slot = atomicAdd(a.det_count + shard, 1u);
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            if (lane == 0 && slot < a.det_cap) {
+                WbDet o = d;
+                o.score = h;
+                a.det[(size_t)shard * a.det_cap + slot] = o;
+            }
+        }
     }
 }
 
@@ -300,46 +447,69 @@ __global__ void boxes_kernel(const WbDet *det, int64_t n_det, const float *inv_s
     scores[i] = d.score;
 }
 
+#define WB_CASC_CONFIGS(X) X(8, 4) X(4, 4) X(2, 4) X(1, 4) X(4, 8) X(2, 8) X(1, 8) X(2, 16) X(1, 16)
+
 template <int D>
-int launch_depth(hipStream_t st, dim3 grid, const CascArgs &a, int rpw, size_t lds) {
-    switch (rpw) {
-        case 8: hipLaunchKernelGGL((cascade_kernel<D, 8>), grid, dim3(256), lds, st, a, a.stages); break;
-        case 4: hipLaunchKernelGGL((cascade_kernel<D, 4>), grid, dim3(256), lds, st, a, a.stages); break;
-        case 2: hipLaunchKernelGGL((cascade_kernel<D, 2>), grid, dim3(256), lds, st, a, a.stages); break;
-        case 1: hipLaunchKernelGGL((cascade_kernel<D, 1>), grid, dim3(256), lds, st, a, a.stages); break;
-        default: wb_set_error("cascade: bad rows-per-wave %d", rpw); return WB_ERR_INVALID;
+int launch_depth(hipStream_t st, dim3 grid, const CascArgs &a, int rpw, int waves, size_t lds, bool deep) {
+    bool launched = false;
+#define WB_X(R, W)                                                                                          \
+    if (!launched && rpw == R && waves == W) {                                                              \
+        hipLaunchKernelGGL((cascade_tile_kernel<D, R, W>), grid, dim3(W * 64), lds, st, a, a.stages);       \
+        launched = true;                                                                                    \
+    }
+    WB_CASC_CONFIGS(WB_X)
+#undef WB_X
+    if (!launched) {
+        wb_set_error("cascade: no kernel for rows-per-wave %d x %d waves", rpw, waves);
+        return WB_ERR_INVALID;
+    }
+    if (deep) {
+        // fixed grid (no host read-back of the queue length): 16 workgroups per shard walk it
+        hipLaunchKernelGGL((cascade_deep_kernel<D>), dim3(WB_DET_SHARDS * 16), dim3(256), 0, st, a);
     }
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;
 }
 
-template <int D, int RPW> int set_lds_attr() {
-    WB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&cascade_kernel<D, RPW>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    return WB_OK;
+template <int D>
+int prepare_depth(int rpw, int waves) {
+#define WB_X(R, W)                                                                                          \
+    if (rpw == R && waves == W) {                                                                           \
+        WB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&cascade_tile_kernel<D, R, W>),     \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));          \
+        return WB_OK;                                                                                       \
+    }
+    WB_CASC_CONFIGS(WB_X)
+#undef WB_X
+    wb_set_error("cascade: no kernel for rows-per-wave %d x %d waves", rpw, waves);
+    return WB_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
-int wb_cascade_prepare(int depth, int rpw) {
-#define WB_CASE(D, R) if (depth == D && rpw == R) return set_lds_attr<D, R>();
-    WB_CASE(1, 8) WB_CASE(1, 4) WB_CASE(1, 2) WB_CASE(1, 1)
-    WB_CASE(2, 8) WB_CASE(2, 4) WB_CASE(2, 2) WB_CASE(2, 1)
-    WB_CASE(3, 8) WB_CASE(3, 4) WB_CASE(3, 2) WB_CASE(3, 1)
-#undef WB_CASE
-    wb_set_error("cascade: no kernel for depth %d / rows-per-wave %d", depth, rpw);
+int wb_cascade_group(int depth) { return depth >= 3 ? 2 : 4; }
+
+int wb_cascade_prepare(int depth, int rpw, int waves) {
+    switch (depth) {
+        case 1: return prepare_depth<1>(rpw, waves);
+        case 2: return prepare_depth<2>(rpw, waves);
+        case 3: return prepare_depth<3>(rpw, waves);
+    }
+    wb_set_error("cascade: no kernel for depth %d", depth);
     return WB_ERR_UNSUPPORTED;
 }
 
 extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const float *chn, int64_t chn_stride,
                                  int layout, int batch, const WbLevel *levels, int n_levels,
                                  const WbTile *tiles, int n_tiles, WbDet *det, uint32_t *det_count,
-                                 uint32_t capacity, uint32_t *alive) {
+                                 uint32_t shard_capacity, WbDet *work, uint32_t *work_count, uint32_t *alive) {
     WB_REQUIRE(model && chn && levels && tiles && det_count && alive, "wb_cascade_launch: null pointer");
-    WB_REQUIRE(det || capacity == 0, "wb_cascade_launch: det is null but capacity > 0");
+    WB_REQUIRE(det || shard_capacity == 0, "wb_cascade_launch: det is null but capacity > 0");
     WB_REQUIRE(batch >= 1 && batch <= 65535, "wb_cascade_launch: batch %d out of range", batch);
     WB_REQUIRE(n_levels >= 1 && n_tiles >= 1, "wb_cascade_launch: empty launch");
     WB_REQUIRE(layout == WB_LAYOUT_PLANAR || layout == WB_LAYOUT_HWC, "wb_cascade_launch: bad layout %d", layout);
+    const bool deep = model->t_tile < model->n_stages;
+    WB_REQUIRE(!deep || (work && work_count), "wb_cascade_launch: this cascade needs the work queue (work, work_count)");
     CascArgs a;
     a.chn = chn;
     a.chn_stride = chn_stride;
@@ -348,22 +518,27 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const float
     a.tiles = tiles;
     a.n_levels = n_levels;
     a.stages = model->stages_dev;
+    a.stages_feat = model->stages_feat_dev;
     a.T = model->n_stages;
+    a.t_tile = model->t_tile;
     a.m = model->m;
     a.n = model->n;
     a.C = model->C;
     a.lds_rows = model->lds_rows;
     a.lds_pitch = model->lds_pitch;
+    a.out = deep ? work : det;
+    a.out_count = deep ? work_count : det_count;
+    a.out_cap = shard_capacity;
     a.det = det;
     a.det_count = det_count;
-    a.capacity = capacity;
+    a.det_cap = shard_capacity;
     a.alive = alive;
     dim3 grid((unsigned)n_tiles, (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;
     switch (model->depth) {
-        case 1: return launch_depth<1>(st, grid, a, model->rpw, (size_t)model->lds_bytes);
-        case 2: return launch_depth<2>(st, grid, a, model->rpw, (size_t)model->lds_bytes);
-        case 3: return launch_depth<3>(st, grid, a, model->rpw, (size_t)model->lds_bytes);
+        case 1: return launch_depth<1>(st, grid, a, model->rpw, model->waves, (size_t)model->lds_bytes, deep);
+        case 2: return launch_depth<2>(st, grid, a, model->rpw, model->waves, (size_t)model->lds_bytes, deep);
+        case 3: return launch_depth<3>(st, grid, a, model->rpw, model->waves, (size_t)model->lds_bytes, deep);
     }
     wb_set_error("wb_cascade_launch: model depth %d has no kernel", model->depth);
     return WB_ERR_UNSUPPORTED;

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
     const T *src = (L.oct == 0) ? (const T *)a.img + (int64_t)b * a.img_stride
                                 : (const T *)a.oct + (int64_t)b * a.oct_stride + L.src_off;
     const uint32_t *mm = a.minmax + ((int64_t)b * a.n_oct + L.oct) * 2;
-    const double mn = Src<T>::lo(mm[0]), mx = Src<T>::lo(mm[1]);
+    const double mn = Src<T>::lo(~mm[0]), mx = Src<T>::lo(mm[1]);   // mm[0] holds max(~key)
 
     // ---- step 0: per-row / per-column resampling taps (coordinates clamped = 'reflect'
     //      halo of convolve1d for a 1-pixel border)

@@ -46,7 +46,6 @@ __host__ __device__ inline float wb_key_f32(uint32_t k) {
 
 // ---- cascade geometry ----
 #define WB_CASC_TC 64        // windows per tile row = one per lane
-#define WB_CASC_WAVES 4      // waves per workgroup
 #define WB_CASC_MAX_DEPTH 3
 
 // The canonical stage record the cascade kernels read with scalar loads:
@@ -62,11 +61,13 @@ __host__ __device__ inline float wb_key_f32(uint32_t k) {
 struct WbModel {
     int n_stages, depth, m, n, C;
     int rpw;          // window rows per wave in the cascade tile
-    int tile_rows;    // = rpw * WB_CASC_WAVES
+    int waves;        // wavefronts per workgroup
+    int tile_rows;    // = rpw * waves
     int lds_rows;     // tile_rows + m - 1
     int lds_pitch;    // (WB_CASC_TC + n - 1) rounded up to 4 floats
     int lds_bytes;
     int stage_dwords;
-    int32_t *stages_dev;   // n_stages * stage_dwords dwords
-    // generic-node copy for wb_tree_eval style walks is not kept here
+    int t_tile;                 // stages run by the tile kernel; the rest go to the deep kernel
+    int32_t *stages_dev;        // (n_stages + G) records with LDS float offsets (tile kernel)
+    int32_t *stages_feat_dev;   // n_stages records with packed (row | col<<8 | channel<<16) (deep kernel)
 };

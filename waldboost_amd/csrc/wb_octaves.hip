@@ -1,10 +1,24 @@
 // Octave pyramid of the raw image (reference channels.py:93-101 + avg_pool_2 :55-64)
 // and the per-octave min/max that skimage.resize clips its output to (channels.py:132).
 //
-// HBM-bound integer/byte work: every octave is read once and written once.
+// HBM-bound integer/byte work: the image is read once, every octave is written once.
+// One workgroup owns a 128x128 block of octave 0 and derives its share of octaves 1..7
+// hierarchically in LDS (a 2^k x 2^k block of octave 0 fully determines one pixel of octave k,
+// odd tails included, because floor(floor(h/2)/2) = floor(h/4)); octaves >= 8 of very large
+// images come from a one-workgroup tail kernel.  min/max are reduced per workgroup and leave
+// with two atomics per octave.
+//
+// minmax encoding: mm[0] = max over ~key(pixel)  (so min key = ~mm[0]),  mm[1] = max over key;
+// both are plain atomicMax on a zero-initialised word, so the buffer is reset with one memset.
 #include "wb_common.h"
 
 namespace {
+
+// block side at octave 0 and the number of octaves derived inside the block: 128 -> octaves
+// 1..7 for bytes (20 KiB of LDS), 64 -> 1..6 for float32 (20 KiB)
+template <typename T> struct Blk;
+template <> struct Blk<uint8_t> { static constexpr int OB = 128, LEVELS = 7; };
+template <> struct Blk<float> { static constexpr int OB = 64, LEVELS = 6; };
 
 template <typename T> struct PixKey;
 template <> struct PixKey<uint8_t> {
@@ -13,40 +27,6 @@ template <> struct PixKey<uint8_t> {
 template <> struct PixKey<float> {
     static __device__ uint32_t key(float v) { return wb_f32_key(v); }
 };
-
-__device__ inline void wave_minmax_commit(uint32_t lo, uint32_t hi, uint32_t *mm) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
-        lo = l2 < lo ? l2 : lo;
-        hi = h2 > hi ? h2 : hi;
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(mm + 0, lo);
-        atomicMax(mm + 1, hi);
-    }
-}
-
-__global__ void minmax_init_kernel(uint32_t *mm, int n_pairs) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_pairs) {
-        mm[2 * i + 0] = 0xffffffffu;
-        mm[2 * i + 1] = 0u;
-    }
-}
-
-// min/max of octave 0 (the image itself); grid = (blocks, batch), grid-stride over pixels.
-template <typename T>
-__global__ void minmax_kernel(const T *img, int64_t img_stride, int64_t n_px, uint32_t *mm, int n_oct) {
-    const T *p = img + (int64_t)blockIdx.y * img_stride;
-    uint32_t lo = 0xffffffffu, hi = 0u;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_px; i += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t k = PixKey<T>::key(p[i]);
-        lo = k < lo ? k : lo;
-        hi = k > hi ? k : hi;
-    }
-    wave_minmax_commit(lo, hi, mm + ((int64_t)blockIdx.y * n_oct + 0) * 2);
-}
 
 template <typename T> __device__ inline T pool4(T a, T b, T c, T d);
 // uint8: the reference's adds are uint8 ufunc adds (wrap mod 256), then /4 in fp64 and a
@@ -59,56 +39,173 @@ template <> __device__ inline float pool4<float>(float a, float b, float c, floa
     return (((a + b) + c) + d) * 0.25f;
 }
 
-// dst[i][j] = pool(src[2i][2j], src[2i+1][2j], src[2i][2j+1], src[2i+1][2j+1]); odd tail dropped.
-template <typename T>
-__global__ void pool2_kernel(const T *src, int64_t src_stride, int sh, int sw, T *dst, int64_t dst_stride,
-                             uint32_t *mm, int n_oct, int oct_k) {
-    const int dh = sh >> 1, dw = sw >> 1;
-    const T *s = src + (int64_t)blockIdx.y * src_stride;
-    T *d = dst + (int64_t)blockIdx.y * dst_stride;
-    const int64_t n = (int64_t)dh * dw;
-    uint32_t lo = 0xffffffffu, hi = 0u;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int r = (int)(i / dw), c = (int)(i - (int64_t)r * dw);
-        const T *p0 = s + (int64_t)(2 * r) * sw + 2 * c;
-        const T *p1 = p0 + sw;
-        T v = pool4<T>(p0[0], p1[0], p0[1], p1[1]);
-        d[i] = v;
-        uint32_t k = PixKey<T>::key(v);
-        lo = k < lo ? k : lo;
-        hi = k > hi ? k : hi;
+// workgroup reduction of (lo-as-~key max, hi max) -> two atomics by thread 0
+__device__ inline void block_minmax_commit(uint32_t nlo, uint32_t hi, uint32_t *red, uint32_t *mm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t l2 = __shfl_xor(nlo, o), h2 = __shfl_xor(hi, o);
+        nlo = l2 > nlo ? l2 : nlo;
+        hi = h2 > hi ? h2 : hi;
     }
-    wave_minmax_commit(lo, hi, mm + ((int64_t)blockIdx.y * n_oct + oct_k) * 2);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[2 * wave] = nlo;
+        red[2 * wave + 1] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+            nlo = red[2 * w] > nlo ? red[2 * w] : nlo;
+            hi = red[2 * w + 1] > hi ? red[2 * w + 1] : hi;
+        }
+        atomicMax(mm + 0, nlo);
+        atomicMax(mm + 1, hi);
+    }
+    __syncthreads();
+}
+
+struct OctDims {
+    int h[WB_MAX_OCTAVES], w[WB_MAX_OCTAVES];
+    int64_t off[WB_MAX_OCTAVES];
+};
+
+// grid = (blocks_x * blocks_y, batch); block = 256 threads
+template <typename T>
+__global__ __launch_bounds__(256) void octaves_block_kernel(const T *img, int64_t img_stride, T *oct, int64_t oct_stride,
+                                                            OctDims d, int n_oct, int blocks_x, uint32_t *minmax) {
+    constexpr int OB = Blk<T>::OB, OB_LEVELS = Blk<T>::LEVELS;
+    __shared__ T bufA[OB * OB];
+    __shared__ T bufB[(OB / 2) * (OB / 2)];
+    __shared__ uint32_t red[8];
+
+    const int b = blockIdx.y;
+    const int by = blockIdx.x / blocks_x, bx = blockIdx.x - by * blocks_x;
+    const int tid = threadIdx.x;
+    const T *src = img + (int64_t)b * img_stride;
+    T *obase = oct + (int64_t)b * oct_stride;
+    uint32_t *mm = minmax + (int64_t)b * n_oct * 2;
+
+    // ---- octave 0 block -> LDS, with its min/max (all pixels, odd tails included)
+    const int H = d.h[0], W = d.w[0];
+    const int y0 = by * OB, x0 = bx * OB;
+    uint32_t nlo = 0u, hi = 0u;
+    for (int i = tid; i < OB * OB; i += 256) {
+        int r = i / OB, c = i - r * OB;
+        int y = y0 + r, x = x0 + c;
+        T v = T(0);
+        if (y < H && x < W) {
+            v = src[(int64_t)y * W + x];
+            uint32_t k = PixKey<T>::key(v);
+            nlo = (~k) > nlo ? (~k) : nlo;
+            hi = k > hi ? k : hi;
+        }
+        bufA[i] = v;
+    }
+    __syncthreads();
+    block_minmax_commit(nlo, hi, red, mm);
+
+    // ---- octaves 1..7: pool LDS -> LDS (+ global), ping-pong between bufA and bufB
+    T *cur = bufA;
+    T *nxt = bufB;
+    int side = OB;                       // side of `cur`
+    const int kmax = n_oct - 1 < OB_LEVELS ? n_oct - 1 : OB_LEVELS;
+    for (int k = 1; k <= kmax; ++k) {
+        const int ns = side >> 1;
+        const int oh = d.h[k], ow = d.w[k];
+        const int oy0 = y0 >> k, ox0 = x0 >> k;
+        T *dst = obase + d.off[k];
+        nlo = 0u;
+        hi = 0u;
+        for (int i = tid; i < ns * ns; i += 256) {
+            int r = i / ns, c = i - r * ns;
+            const T *p0 = cur + (2 * r) * side + 2 * c;
+            T v = pool4<T>(p0[0], p0[side], p0[1], p0[side + 1]);
+            nxt[r * ns + c] = v;
+            int y = oy0 + r, x = ox0 + c;
+            if (y < oh && x < ow) {
+                dst[(int64_t)y * ow + x] = v;
+                uint32_t key = PixKey<T>::key(v);
+                nlo = (~key) > nlo ? (~key) : nlo;
+                hi = key > hi ? key : hi;
+            }
+        }
+        __syncthreads();
+        block_minmax_commit(nlo, hi, red, mm + 2 * k);
+        T *t = cur;
+        cur = nxt;
+        nxt = t;
+        side = ns;
+    }
+}
+
+// octaves beyond the block's reach (bytes: images of 2048+ px on the short side): one workgroup per image walks
+// the remaining octaves in LDS, starting from octave 7 in HBM (written by the launch before).
+template <typename T>
+__global__ __launch_bounds__(256) void octaves_tail_kernel(T *oct, int64_t oct_stride, OctDims d, int n_oct,
+                                                           uint32_t *minmax) {
+    constexpr int OB_LEVELS = Blk<T>::LEVELS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tail_smem[];
+    __shared__ uint32_t red[8];
+    T *cur = reinterpret_cast<T *>(tail_smem);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    T *obase = oct + (int64_t)b * oct_stride;
+    uint32_t *mm = minmax + (int64_t)b * n_oct * 2;
+    int sh = d.h[OB_LEVELS], sw = d.w[OB_LEVELS];
+    T *nxt = cur + sh * sw;
+    for (int i = tid; i < sh * sw; i += 256) cur[i] = obase[d.off[OB_LEVELS] + i];
+    __syncthreads();
+    for (int k = OB_LEVELS + 1; k < n_oct; ++k) {
+        const int oh = d.h[k], ow = d.w[k];
+        T *dst = obase + d.off[k];
+        uint32_t nlo = 0u, hi = 0u;
+        for (int i = tid; i < oh * ow; i += 256) {
+            int r = i / ow, c = i - r * ow;
+            const T *p0 = cur + (2 * r) * sw + 2 * c;
+            T v = pool4<T>(p0[0], p0[sw], p0[1], p0[sw + 1]);
+            nxt[i] = v;
+            dst[i] = v;
+            uint32_t key = PixKey<T>::key(v);
+            nlo = (~key) > nlo ? (~key) : nlo;
+            hi = key > hi ? key : hi;
+        }
+        __syncthreads();
+        block_minmax_commit(nlo, hi, red, mm + 2 * k);
+        T *t = cur;
+        cur = nxt;
+        nxt = t;
+        sh = oh;
+        sw = ow;
+    }
 }
 
 template <typename T>
 int launch_octaves(hipStream_t st, const T *img, int batch, int H, int W, int64_t img_stride, T *oct,
                    int64_t oct_stride, const int64_t *oct_off, int n_oct, uint32_t *minmax) {
-    const int threads = 256;
-    int n_pairs = batch * n_oct;
-    hipLaunchKernelGGL(minmax_init_kernel, dim3((n_pairs + threads - 1) / threads), dim3(threads), 0, st, minmax, n_pairs);
-    {
-        int64_t n_px = (int64_t)H * W;
-        int blocks = (int)((n_px + threads * 8 - 1) / (threads * 8));
-        if (blocks > 2048) blocks = 2048;
-        if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(minmax_kernel<T>, dim3(blocks, batch), dim3(threads), 0, st, img, img_stride, n_px, minmax, n_oct);
+    OctDims d;
+    int h = H, w = W;
+    for (int k = 0; k < n_oct; ++k) {
+        d.h[k] = h;
+        d.w[k] = w;
+        d.off[k] = k ? oct_off[k] : 0;
+        h >>= 1;
+        w >>= 1;
     }
-    int sh = H, sw = W;
-    const T *src = img;
-    int64_t sstride = img_stride;
-    for (int k = 1; k < n_oct; ++k) {
-        T *dst = oct + oct_off[k];
-        int64_t n = (int64_t)(sh >> 1) * (sw >> 1);
-        int blocks = (int)((n + threads - 1) / threads);
-        if (blocks > 4096) blocks = 4096;
-        if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(pool2_kernel<T>, dim3(blocks, batch), dim3(threads), 0, st, src, sstride, sh, sw, dst,
-                           oct_stride, minmax, n_oct, k);
-        src = dst;
-        sstride = oct_stride;
-        sh >>= 1;
-        sw >>= 1;
+    constexpr int OB = Blk<T>::OB, OB_LEVELS = Blk<T>::LEVELS;
+    WB_HIP_CHECK(hipMemsetAsync(minmax, 0, sizeof(uint32_t) * 2 * (size_t)batch * n_oct, st));
+    const int bx = (W + OB - 1) / OB, by = (H + OB - 1) / OB;
+    hipLaunchKernelGGL(octaves_block_kernel<T>, dim3(bx * by, batch), dim3(256), 0, st, img, img_stride, oct, oct_stride,
+                       d, n_oct, bx, minmax);
+    if (n_oct > OB_LEVELS + 1) {
+        size_t px = (size_t)d.h[OB_LEVELS] * d.w[OB_LEVELS];
+        size_t lds = (px + px / 4 + 16) * sizeof(T);
+        if (lds > 150 * 1024) {
+            wb_set_error("wb_octaves_launch: %dx%d image too large for the octave tail kernel", H, W);
+            return WB_ERR_UNSUPPORTED;
+        }
+        if (lds > 48 * 1024)
+            WB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&octaves_tail_kernel<T>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(octaves_tail_kernel<T>, dim3(batch), dim3(256), lds, st, oct, oct_stride, d, n_oct, minmax);
     }
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;
@@ -120,7 +217,7 @@ extern "C" int wb_octaves_launch(void *stream, const void *img, int dtype, int b
                                  int64_t img_stride, void *oct, int64_t oct_stride, const int64_t *oct_off,
                                  int n_oct, uint32_t *minmax) {
     WB_REQUIRE(img && minmax, "wb_octaves_launch: null pointer");
-    WB_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "wb_octaves_launch: bad shape batch=%d H=%d W=%d", batch, H, W);
+    WB_REQUIRE(batch >= 1 && batch <= 65535 && H >= 1 && W >= 1, "wb_octaves_launch: bad shape batch=%d H=%d W=%d", batch, H, W);
     WB_REQUIRE(n_oct >= 1 && n_oct <= WB_MAX_OCTAVES, "wb_octaves_launch: n_oct=%d out of range", n_oct);
     WB_REQUIRE(n_oct == 1 || (oct && oct_off), "wb_octaves_launch: octave buffer missing");
     // the octave chain must match reference channels.py:93-101 (halve until w<8 or h<8)

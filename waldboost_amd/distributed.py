@@ -18,39 +18,39 @@ def shard_range(n_items, rank, world):
 
 
 class DetectionGatherer:
-    """All-gathers the first `cap`+1 rows of each rank's detection buffer (row 0 = header with
-    the count, rows 1.. = WbDet records as 4 int32 words)."""
+    """All-gathers every rank's sharded detection buffer (engine.DetBuffer.buf: counters in the
+    first rows, WbDet records after) -- one fixed-size collective, no host read-back of counts."""
 
-    def __init__(self, cap, device, group=None):
+    def __init__(self, detb, group=None):
         import torch
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.cap = int(cap)
-        self.recv = torch.zeros((self.world, self.cap + 1, 4), dtype=torch.int32, device=device)
+        self.NS, self.cap = detb.NS, detb.cap
+        self.rows = detb.buf.shape[0]
+        self.recv = torch.zeros((self.world * self.rows, 4), dtype=torch.int32, device=detb.buf.device)
 
-    def gather(self, det_buf, async_op=False):
-        """det_buf: int32 [>=cap+1, 4] (PyramidEngine.det_buf).  Returns the work handle (or None)."""
-        send = det_buf[: self.cap + 1]
-        return self.dist.all_gather_into_tensor(self.recv.view(-1, 4), send.contiguous(), group=self.group,
-                                                async_op=async_op)
+    def gather(self, detb, async_op=False):
+        return self.dist.all_gather_into_tensor(self.recv, detb.buf, group=self.group, async_op=async_op)
 
     def merged(self, images_per_rank):
         """Host-side merge on any rank: records of all ranks with image indices made global
-        (rank r's local image i -> sum(images_per_rank[:r]) + i).  Raises if a rank overflowed
-        the gathered prefix."""
+        (rank r's local image i -> sum(images_per_rank[:r]) + i), in reference order.  Raises if
+        a shard overflowed."""
         from ._native import DET_DTYPE
-        recv = self.recv.cpu().numpy()
+        recv = self.recv.cpu().numpy().reshape(self.world, self.rows, 4)
         parts, base = [], 0
         for r in range(self.world):
-            n = int(recv[r, 0, 0]) & 0xFFFFFFFF
-            if n > self.cap:
-                raise OverflowError(f"rank {r} produced {n} detections, gather prefix holds {self.cap}")
-            d = recv[r, 1:1 + n].copy().view(DET_DTYPE).reshape(-1)
-            d["image"] += base
-            parts.append(d)
+            counts = recv[r, : self.NS // 4].reshape(-1).view(np.uint32)
+            if counts.max(initial=0) > self.cap:
+                raise OverflowError(f"rank {r}: a detection shard holds {counts.max()} records, capacity {self.cap}")
+            recs = recv[r, self.NS // 4:].reshape(self.NS, self.cap, 4)
+            for s in range(self.NS):
+                d = recs[s, : counts[s]].copy().view(DET_DTYPE).reshape(-1)
+                d["image"] += base
+                parts.append(d)
             base += int(images_per_rank[r])
         out = np.concatenate(parts) if parts else np.zeros(0, DET_DTYPE)
         order = np.lexsort((out["c"], out["r"], out["level"], out["image"]))

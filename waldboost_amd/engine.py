@@ -85,6 +85,7 @@ class DeviceCascade:
         self.n_stages, self.depth = info.n_stages, info.depth
         self.m, self.n, self.C = info.m, info.n, info.C
         self.tile_rows, self.tile_cols, self.lds_bytes = info.tile_rows, info.tile_cols, info.lds_bytes
+        self.handoff_stage = info.handoff_stage
 
     def __del__(self):
         try:
@@ -95,9 +96,48 @@ class DeviceCascade:
             pass
 
 
+class DetBuffer:
+    """Sharded append buffer of WbDet records (include/waldboost_hip.h: WB_DET_SHARDS regions of
+    `cap` records, one counter each).  One contiguous int32 [NS/4 + NS*cap, 4] block: the first
+    NS/4 rows are the NS counters, the records follow -- so the whole thing can be handed to a
+    collective as is."""
+
+    def __init__(self, cap, dev):
+        import torch
+        self.NS = nat.WB_DET_SHARDS
+        self.cap = int(cap)
+        self.buf = torch.zeros((self.NS // 4 + self.NS * self.cap, 4), dtype=torch.int32, device=dev)
+        self.counts = self.buf[: self.NS // 4].view(-1)
+        self.recs = self.buf[self.NS // 4:]
+
+    def zero(self):
+        self.counts.zero_()
+
+    def max_count(self):
+        return int(self.counts.max().item())
+
+    def compact(self):
+        """All valid records as one int32 [n, 4] tensor (shard order)."""
+        import torch
+        ar = torch.arange(self.cap, device=self.buf.device, dtype=torch.int32)
+        mask = ar[None, :] < self.counts[:, None].clamp(max=self.cap)
+        return self.recs.view(self.NS, self.cap, 4)[mask]
+
+
+def sort_records(d):
+    """Records ordered by (image, level, r, c) -- the reference's output order (row-major window
+    grid, levels in pyramid order)."""
+    import torch
+    if d.shape[0] == 0:
+        return d
+    rc = d[:, 2].to(torch.int64) & 0xFFFFFFFF
+    key = (d[:, 0].to(torch.int64) << 44) | (d[:, 1].to(torch.int64) << 32) | ((rc & 0xFFFF) << 16) | (rc >> 16)
+    return d[torch.argsort(key)].contiguous()
+
+
 class PyramidEngine:
     def __init__(self, H, W, dtype, shrink, n_per_oct, smooth, batch=1, layout=nat.WB_LAYOUT_PLANAR,
-                 exact_single=False, det_capacity=1 << 18):
+                 exact_single=False, det_capacity=1 << 16):
         import torch
         self.lib = nat.load()
         self.dev = nat.require_gpu()
@@ -134,16 +174,18 @@ class PyramidEngine:
             hi = np.array([nat_f32_key(np.inf)], np.uint32).view(np.int32)[0]
             if self.wb_dtype == nat.WB_DTYPE_U8:
                 lo, hi = 0, 255
-            self.minmax[:, :, 0] = int(lo)
+            lo = np.array([~np.uint32(np.array([lo]).astype(np.int64)[0] & 0xFFFFFFFF)], np.uint32).view(np.int32)[0]
+            self.minmax[:, :, 0] = int(lo)   # word 0 stores max(~key), see csrc/wb_octaves.hip
             self.minmax[:, :, 1] = int(hi)
 
     def _alloc_det(self):
-        """Detection buffer: row 0 is a header whose first word is the survivor count, records
-        follow -- one contiguous block, so a fixed-size prefix can be handed to a collective."""
-        import torch
-        self.det_buf = torch.zeros((self.det_capacity + 1, 4), dtype=torch.int32, device=self.dev)
-        self.det_count = self.det_buf[0, 0:1]
-        self.det = self.det_buf[1:]
+        """Detection buffer and the tile->deep work queue (same sharded layout); det_capacity is
+        the total record capacity, split evenly over the shards."""
+        cap = max(16, -(-self.det_capacity // nat.WB_DET_SHARDS))
+        self.det_capacity = cap * nat.WB_DET_SHARDS
+        self.detb = DetBuffer(cap, self.dev)
+        self.workb = DetBuffer(cap, self.dev)
+        self.det_buf = self.detb.buf
 
     # ------------------------------------------------------------------ input
     def load_images(self, images):
@@ -205,15 +247,17 @@ class PyramidEngine:
             return stt
         nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.chn), self.chn_stride,
                                              self.layout, self.batch, nat.ptr(self.levels), self.plan.n_levels,
-                                             nat.ptr(stt["tiles"]), stt["n_tiles"], nat.ptr(self.det),
-                                             nat.ptr(self.det_count), self.det_capacity, nat.ptr(stt["alive"])),
+                                             nat.ptr(stt["tiles"]), stt["n_tiles"], nat.ptr(self.detb.recs),
+                                             nat.ptr(self.detb.counts), self.detb.cap, nat.ptr(self.workb.recs),
+                                             nat.ptr(self.workb.counts), nat.ptr(stt["alive"])),
                   "wb_cascade_launch")
         return stt
 
     def run_cascade(self, dm):
         """Zero the counters and scan every level of every image with cascade `dm`."""
         stt = self._casc_state(dm)
-        self.det_count.zero_()
+        self.detb.zero()
+        self.workb.zero()
         stt["alive"].zero_()
         return self.launch_cascade(dm)
 
@@ -240,27 +284,19 @@ class PyramidEngine:
 
     # ------------------------------------------------------------------ results
     def ensure_capacity(self, dm):
-        """Re-run the cascade with a larger record buffer if the last scan overflowed it."""
-        import torch
-        n = int(self.det_count.item()) & 0xFFFFFFFF
-        while n > self.det_capacity:
-            self.det_capacity = int(n * 1.25) + 1024
+        """Re-run the cascade with larger buffers if a shard of the detection buffer or of the
+        work queue overflowed in the last scan.  Returns the number of detections."""
+        while True:
+            need = max(self.detb.max_count(), self.workb.max_count())
+            if need <= self.detb.cap:
+                return int(self.detb.counts.sum().item())
+            self.det_capacity = (int(need * 1.5) + 16) * nat.WB_DET_SHARDS
             self._alloc_det()
             self.run_cascade(dm)
-            n = int(self.det_count.item()) & 0xFFFFFFFF
-        return n
 
-    def sorted_detections(self, n):
-        """First n records ordered by (image, level, r, c) -- the reference's output order
-        (row-major window grid, levels in pyramid order)."""
-        import torch
-        d = self.det[:n]
-        if n == 0:
-            return d
-        rc = d[:, 2].to(torch.int64) & 0xFFFFFFFF
-        key = (d[:, 0].to(torch.int64) << 44) | (d[:, 1].to(torch.int64) << 32) | ((rc & 0xFFFF) << 16) | (rc >> 16)
-        order = torch.argsort(key)
-        return d[order].contiguous()
+    def sorted_detections(self, n=None):
+        """Detections ordered by (image, level, r, c) as an int32 [n, 4] tensor of WbDet records."""
+        return sort_records(self.detb.compact())
 
     def boxes(self, det_sorted, dm):
         import torch

@@ -149,7 +149,7 @@ class Model:
         eng.load_images(image)
         stt = eng.run(dm)
         n_det = eng.ensure_capacity(dm)
-        det = eng.sorted_detections(n_det)
+        det = eng.sorted_detections()
         boxes, scores = eng.boxes(det, dm)
         alive = stt["alive"][0, :, :T].cpu().numpy().astype(np.int64).reshape(eng.plan.n_levels, T)
         self.n_loc += eng.plan.n_loc(m, n)
@@ -234,9 +234,8 @@ class _SingleLevel:
         t[0]["u"], t[0]["v"], t[0]["vp"], t[0]["chn_off"] = u, v, v, 0
         self.levels = torch.from_numpy(t.view(np.uint8).copy()).to(self.dev)
         self.X = torch.empty((max(u * v * C, 1),), dtype=torch.float32, device=self.dev)
-        self.capacity = 1 << 16
-        self.det = torch.empty((self.capacity, 4), dtype=torch.int32, device=self.dev)
-        self.count = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.detb = _engine.DetBuffer(1 << 10, self.dev)
+        self.workb = _engine.DetBuffer(1 << 10, self.dev)
         self._tiles = {}
 
     def load(self, X):
@@ -257,25 +256,22 @@ class _SingleLevel:
         T = dm.n_stages
         alive = torch.zeros((1, 1, max(T, 1)), dtype=torch.int32, device=self.dev)
         while True:
-            self.count.zero_()
+            self.detb.zero()
+            self.workb.zero()
             alive.zero_()
             if n_tiles:
                 nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.X), 0, nat.WB_LAYOUT_HWC,
                                                      1, nat.ptr(self.levels), 1, nat.ptr(tiles), n_tiles,
-                                                     nat.ptr(self.det), nat.ptr(self.count), self.capacity,
+                                                     nat.ptr(self.detb.recs), nat.ptr(self.detb.counts), self.detb.cap,
+                                                     nat.ptr(self.workb.recs), nat.ptr(self.workb.counts),
                                                      nat.ptr(alive)), "wb_cascade_launch")
-            n = int(self.count.item()) & 0xFFFFFFFF
-            if n <= self.capacity:
+            need = max(self.detb.max_count(), self.workb.max_count())
+            if need <= self.detb.cap:
                 break
-            self.capacity = int(n * 1.25) + 1024
-            self.det = torch.empty((self.capacity, 4), dtype=torch.int32, device=self.dev)
+            self.detb = _engine.DetBuffer(int(need * 1.5) + 16, self.dev)
+            self.workb = _engine.DetBuffer(int(need * 1.5) + 16, self.dev)
+        n = int(self.detb.counts.sum().item())
         return n, alive[0, 0, :T].cpu().numpy().astype(np.int64)
 
     def sorted(self, n):
-        import torch
-        d = self.det[:n]
-        if n == 0:
-            return d
-        rc = d[:, 2].to(torch.int64) & 0xFFFFFFFF
-        key = ((rc & 0xFFFF) << 16) | (rc >> 16)
-        return d[torch.argsort(key)].contiguous()
+        return _engine.sort_records(self.detb.compact())
