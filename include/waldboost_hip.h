@@ -100,8 +100,6 @@ typedef struct WbModelInfo {
     int32_t tile_rows;  /* cascade tile: tile_rows x 64 windows per workgroup      */
     int32_t tile_cols;
     int32_t lds_bytes;  /* dynamic LDS per workgroup of the cascade kernel         */
-    int32_t handoff_stage; /* stages [0, handoff) run in the tile kernel, the rest in the
-                              deep kernel; == n_stages when the cascade is not split    */
 } WbModelInfo;
 
 int wb_abi_version(void);
@@ -155,18 +153,13 @@ int wb_model_info(const WbModel *model, WbModelInfo *info);
  *   det           dev WbDet[WB_DET_SHARDS][shard_capacity]; det_count dev uint32[WB_DET_SHARDS]:
  *                 survivors per shard (a count may exceed shard_capacity: the records beyond it
  *                 are dropped, the count stays exact -- grow the buffer and launch again)
- *   work          dev WbDet[WB_DET_SHARDS][shard_capacity] + work_count uint32[WB_DET_SHARDS]:
- *                 queue between the tile kernel (first stages, LDS-tiled) and the deep kernel
- *                 (remaining stages, one wavefront per surviving window); only used by cascades
- *                 long enough to be split (WbModelInfo.handoff_stage < n_stages), may be NULL
- *                 otherwise.  An overflowing work shard loses windows: check work_count too.
  *   alive         dev uint32 [batch][n_levels][n_stages]: windows entering each stage
- * det_count, work_count and alive are ACCUMULATED into: the caller zeroes them.  Record order
+ * det_count and alive are ACCUMULATED into: the caller zeroes them.  Record order
  * is unspecified; sort by (image, level, r, c) to obtain the reference order. */
 int wb_cascade_launch(void *stream, const WbModel *model, const float *chn, int64_t chn_stride,
                       int layout, int batch, const WbLevel *levels, int n_levels,
                       const WbTile *tiles, int n_tiles, WbDet *det, uint32_t *det_count,
-                      uint32_t shard_capacity, WbDet *work, uint32_t *work_count, uint32_t *alive);
+                      uint32_t shard_capacity, uint32_t *alive);
 
 /* One tree evaluated at explicit window origins (rs[i], cs[i]) of an HWC channel image
  * X[u][v][C]; out[i] = prediction of the leaf reached (training.py:84-96). Tree arrays
@@ -180,6 +173,12 @@ int wb_tree_eval_launch(void *stream, const float *X, int u, int v, int C, const
  *   inv_scale  dev float[n_levels] = float32(1.0/scale) computed on the host in fp64 */
 int wb_boxes_launch(void *stream, const WbDet *det, int64_t n_det, const float *inv_scale,
                     int m, int n, float *boxes /* [n_det][4] */, float *scores /* [n_det] */);
+
+/* Device self-test: the uint8 fast path of the orientation projection (fp32 arithmetic that is
+ * proven equal to the reference's fp64 formula for integer gradients) is compared with the fp64
+ * formula for every (gx, gy) in [-1020, 1020]^2; *mismatches (dev uint32, zeroed by the caller)
+ * receives the number of differing channel values -- must stay 0. */
+int wb_selftest_projection(void *stream, uint32_t *mismatches);
 
 #ifdef __cplusplus
 }

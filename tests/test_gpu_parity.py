@@ -255,25 +255,43 @@ def test_octaves_and_clip_range_vs_oracle(shape, dtype):
             assert lo_key == nat_f32_key(o.min()) and hi_key == nat_f32_key(o.max()), k
 
 
-# ------------------------------------------------------------------------------ split cascade
-@pytest.mark.parametrize("depth,T,handoff", [(2, 70, None), (1, 100, None), (3, 66, None), (2, 50, "8"), (2, 130, "64"),
-                                             (2, 90, "0")])
-def test_long_cascades_split_between_tile_and_deep_kernel(depth, T, handoff, monkeypatch):
-    """Cascades longer than handoff+16 stages finish in the stage-parallel deep kernel; the
-    hand-off stage must not change any result (WB_CASC_HANDOFF=8 floods the work queue and
-    forces the buffers to grow, =0 disables the split)."""
-    if handoff is not None:
-        monkeypatch.setenv("WB_CASC_HANDOFF", handoff)
+# ------------------------------------------------------------------------------ long cascades
+@pytest.mark.parametrize("depth,T,floor", [(2, 70, -1.0), (1, 100, -1.0), (3, 66, -1.0), (2, 50, -30.0), (2, 130, -0.2),
+                                           (2, 200, -1.0)])
+def test_long_cascades_wave_synchronous_and_stage_parallel_tails(depth, T, floor):
+    """Past stage 16 a wave with <= 8 windows left switches to the stage-parallel tail (one stage
+    per lane, serial fp32 replay); crowded waves stay wave-synchronous.  A slowly falling
+    rejection floor keeps a mix of both alive to the last stage (floor=-30 keeps nearly every
+    window: all wave-synchronous, and the detection buffer has to grow)."""
     img = synth_image(260, 380, 50 + T)
     M = random_model(300 + T, T, depth)
-    # mild thresholds (a slowly falling floor) so that a fair share of windows reaches the late stages
-    M.theta = [float(np.float32(-1.0 - 0.3 * i)) if i % 3 == 0 else float("-inf") for i in range(T)]
+    M.theta = [float(np.float32(floor - 0.3 * i)) if i % 3 == 0 else float("-inf") for i in range(T)]
     M._device = None
-    dm = M.device_cascade()
-    expect = T if handoff == "0" else (int(handoff) if handoff else 32)
-    assert dm.handoff_stage == (expect if T > expect + 16 else T)
     res = M.detect_raw(img)
     ref = oracle_detect(M, img)
     assert ref["alive"][:, -1].sum() > 0
     assert_same_detections(res, ref)
     assert M.n_weak == ref["n_weak"]
+
+
+def test_uint8_projection_fast_path_is_exact_for_every_gradient_pair():
+    """project_int (fp32) == project_f64 (the reference's fp64 formula) for all 2041^2 integer
+    gradient pairs a uint8 image can produce -- checked exhaustively on the device."""
+    import torch
+    from waldboost_amd import _native as nat
+    lib = nat.load()
+    dev = nat.require_gpu()
+    mism = torch.zeros(1, dtype=torch.int32, device=dev)
+    nat.check(lib.wb_selftest_projection(nat.stream_ptr(), nat.ptr(mism)), "wb_selftest_projection")
+    assert int(mism.item()) == 0
+
+
+def test_uint8_fast_and_generic_projection_agree(monkeypatch):
+    img = synth_image(333, 517, 91)
+    img[40:90, 100:300] = 255          # saturated flat block and hard edges: gy == 0 / gx == gy lanes
+    img[200:260, 50:120] = 0
+    o = dict(shrink=2, n_per_oct=4, smooth=1, channels=wb.channels.grad_hist)
+    fast = [c.copy() for c, _ in wb.channels.channel_pyramid(img, o)]
+    ref = [c for c, _ in orc.channel_pyramid(img, dict(o, channels=orc.grad_hist))]
+    for a, b in zip(fast, ref):
+        assert np.array_equal(bits(a), bits(b))

@@ -131,11 +131,6 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         return WB_ERR_UNSUPPORTED;
     }
     M->stage_dwords = WB_STAGE_DWORDS(D);
-    // long cascades are split: the LDS-tiled kernel runs the first `handoff` stages, the few
-    // windows that survive them finish in the deep kernel (WB_CASC_HANDOFF overrides, 0 = never)
-    int handoff = 32;
-    if (const char *e = getenv("WB_CASC_HANDOFF")) handoff = atoi(e) & ~3;
-    M->t_tile = (handoff > 0 && n_stages > handoff + 16) ? handoff : n_stages;
 
     // ---- pack and upload the stage records
     const int NI = (1 << D) - 1, NL = 1 << D, SD = M->stage_dwords;
@@ -151,27 +146,12 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         fill(trees[s], 0, 0, 0, D, M->lds_rows, M->lds_pitch, off, thr, pred);
         reinterpret_cast<float *>(rec)[2 * NI + NL] = theta[s];
     }
-    // the same records with features as packed (row | col<<8 | channel<<16): the deep kernel
-    // gathers from the level's own planes in HBM, whose pitch is not known here
-    std::vector<int32_t> packed_feat((size_t)(n_stages + 1) * SD, 0);
-    for (int s = 0; s < n_stages; ++s) {
-        int32_t *rec = packed_feat.data() + (size_t)s * SD;
-        memcpy(rec, packed.data() + (size_t)s * SD, (size_t)SD * 4);
-        for (int i = 0; i < NI; ++i) {
-            int o = packed[(size_t)s * SD + i];
-            int ch = o / (M->lds_rows * M->lds_pitch), rem = o % (M->lds_rows * M->lds_pitch);
-            rec[i] = (rem / M->lds_pitch) | ((rem % M->lds_pitch) << 8) | (ch << 16);
-        }
-    }
     {
         hipError_t e = hipMalloc((void **)&M->stages_dev, packed.size() * 4);
         if (e == hipSuccess) e = hipMemcpy(M->stages_dev, packed.data(), packed.size() * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc((void **)&M->stages_feat_dev, packed_feat.size() * 4);
-        if (e == hipSuccess) e = hipMemcpy(M->stages_feat_dev, packed_feat.data(), packed_feat.size() * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             wb_set_error("wb_model_create: uploading %zu stage bytes failed: %s", packed.size() * 4, hipGetErrorString(e));
             if (M->stages_dev) (void)hipFree(M->stages_dev);
-            if (M->stages_feat_dev) (void)hipFree(M->stages_feat_dev);
             delete M;
             return WB_ERR_HIP;
         }
@@ -179,7 +159,6 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
     int rc = wb_cascade_prepare(D, M->rpw, M->waves);
     if (rc != WB_OK) {
         if (M->stages_dev) (void)hipFree(M->stages_dev);
-        if (M->stages_feat_dev) (void)hipFree(M->stages_feat_dev);
         delete M;
         return rc;
     }
@@ -190,7 +169,6 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
 extern "C" int wb_model_destroy(WbModel *model) {
     if (!model) return WB_OK;
     if (model->stages_dev) (void)hipFree(model->stages_dev);
-    if (model->stages_feat_dev) (void)hipFree(model->stages_feat_dev);
     delete model;
     return WB_OK;
 }
@@ -205,6 +183,5 @@ extern "C" int wb_model_info(const WbModel *model, WbModelInfo *info) {
     info->tile_rows = model->tile_rows;
     info->tile_cols = WB_CASC_TC;
     info->lds_bytes = model->lds_bytes;
-    info->handoff_stage = model->t_tile;
     return WB_OK;
 }

@@ -4,30 +4,26 @@
 // rejection, compaction, n_loc/n_weak statistics) and training.py:84-96
 // (DTree.predict_on_image: the tree walk on all alive windows).
 //
-// Two kernels:
-//
-// tile kernel  -- stages [0, S_h).  One workgroup owns a tile of TR x 64 windows of one level of
-//   one image:
+// One workgroup owns a tile of TR x 64 windows of one level of one image:
 //   * the (TR+m-1) x (64+n-1) x C channel block is staged once into LDS, planar, so that a
 //     wavefront's 64 lanes (64 adjacent window columns) gather from 64 adjacent banks;
-//   * the stage loop is wave-synchronous: every lane of a wave is at the same stage, so the
-//     stage records come in through the scalar cache (s_load) and cost no vector memory or LDS
-//     traffic; stages are evaluated in groups of G with all 2*G gathers in flight (only the
-//     fp32 accumulation and the rejection tests are sequential);
+//   * wave-synchronous stages: every lane of a wave is at the same stage, so the stage records
+//     come in through the scalar cache (s_load) and cost no vector memory or LDS traffic; stages
+//     are evaluated in groups of G with all 2*G gathers in flight (only the fp32 accumulation
+//     and the rejection tests are sequential);
 //   * phase A runs the first stages with RPW windows per lane; survivors are compacted with
 //     wave ballot + mbcnt into the wave's own LDS queue; phase B re-packs them densely for
 //     geometrically growing stage segments, compacting in place after each segment;
-//   * the windows still alive after stage S_h-1 stay in the wave's queue; one thread then
-//     reserves room for the whole workgroup with ONE atomic on one of WB_DET_SHARDS counters
-//     and the waves copy their records out.
-//
-// deep kernel  -- stages [S_h, T), only when the cascade is much longer than S_h.
-//   Few windows get this far (about 1e-3 for the benchmark cascade) but they have ~100 stages
-//   to go; kept in the tile kernel they would pin a workgroup's LDS tile for the whole serial
-//   walk.  Here one wavefront takes one survivor and evaluates 64 stages AT ONCE, one stage per
-//   lane (stage records and feature gathers straight from HBM/L2), then replays the fp32
-//   accumulation and the rejection tests serially in stage order with v_readlane -- the same
-//   additions in the same order as the reference, so scores stay bit-identical.
+//   * stage-parallel tail: once a wave is down to a handful of windows (about 1e-3 of the
+//     windows of the benchmark cascade reach stage 32, with ~100 stages to go) the roles flip:
+//     one window at a time, 64 stages AT ONCE, one stage per lane (per-lane stage records,
+//     gathers from the same LDS tile); the fp32 accumulation and the rejection tests are then
+//     replayed in stage order -- lane i adds p_0 .. p_i one after the other, exactly the
+//     reference's running sum -- so a nearly empty wave no longer walks 100 stages serially
+//     while the workgroup's LDS tile sits idle;
+//   * the windows alive after the last stage stay in the wave's queue; one thread reserves room
+//     for the whole workgroup with ONE atomic on one of WB_DET_SHARDS counters and the waves
+//     copy their records out.
 //
 // Scores are accumulated in fp32 strictly in stage order and compared with `>=`, so they are
 // bit-identical to the reference's `hs += ...; mask = hs >= theta`.
@@ -42,15 +38,10 @@ struct CascArgs {
     const WbLevel *levels;
     const WbTile *tiles;
     int n_levels;
-    const int32_t *stages;      // LDS-offset records (tile kernel)
-    const int32_t *stages_feat; // packed (row, col, channel) records (deep kernel)
+    const int32_t *stages;      // stage records with LDS float offsets
     int T, m, n, C;
-    int t_tile;                 // stages run by the tile kernel (S_h, or T when there is no deep kernel)
     int lds_rows, lds_pitch;
-    WbDet *out;                 // where the tile kernel appends: work queue or detections
-    uint32_t *out_count;
-    uint32_t out_cap;           // per shard
-    WbDet *det;                 // deep kernel output
+    WbDet *det;
     uint32_t *det_count;
     uint32_t det_cap;           // per shard
     uint32_t *alive;
@@ -58,20 +49,20 @@ struct CascArgs {
 
 __device__ inline float as_f(int32_t x) { return __int_as_float(x); }
 
+// a[path] for the root-to-node path bits[0..] (false = left, true = right), first decision first
 template <int N, typename V> struct Sel {
-    // a[path] for path in [0, N) with the first decision in the most significant bit
-    static __device__ inline V get(const V *a, int path) {
-        V lo = Sel<N / 2, V>::get(a, path);
-        V hi = Sel<N / 2, V>::get(a + N / 2, path);
-        return (path & (N / 2)) ? hi : lo;
+    static __device__ inline V get(const V *a, const bool *bits) {
+        V lo = Sel<N / 2, V>::get(a, bits + 1);
+        V hi = Sel<N / 2, V>::get(a + N / 2, bits + 1);
+        return bits[0] ? hi : lo;
     }
 };
 template <typename V> struct Sel<1, V> {
-    static __device__ inline V get(const V *a, int) { return a[0]; }
+    static __device__ inline V get(const V *a, const bool *) { return a[0]; }
 };
 
-// The stage record (see wb_common.h), pulled into SGPRs by the tile kernel (wave-uniform
-// address).
+// The stage record (see wb_common.h): in SGPRs when every lane is at the same stage
+// (wave-uniform address -> s_load), in VGPRs in the stage-parallel tail (one stage per lane).
 template <int D> struct Stage {
     static constexpr int NI = WB_STAGE_NI(D), NL = WB_STAGE_NL(D);
     int off[NI];
@@ -87,19 +78,28 @@ template <int D> struct Stage {
         for (int i = 0; i < NL; ++i) pred[i] = as_f(sp[2 * NI + i]);
         theta = as_f(sp[2 * NI + NL]);
     }
-    template <int d> __device__ inline int step(const float *tile, int base, int path) const {
-        constexpr int first = (1 << d) - 1;
-        int o = Sel<(1 << d), int>::get(off + first, path);
-        float th = Sel<(1 << d), float>::get(thr + first, path);
-        float v = tile[base + o];
-        return 2 * path + ((v <= th) ? 0 : 1);   // NaN goes right, like the reference's `<=`
-    }
     // walk the complete depth-D tree for the window whose origin is tile[base]
     __device__ inline float eval(const float *tile, int base) const {
-        int path = step<0>(tile, base, 0);
-        if constexpr (D > 1) path = step<1>(tile, base, path);
-        if constexpr (D > 2) path = step<2>(tile, base, path);
-        return Sel<NL, float>::get(pred, path);
+        bool right[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) right[d] = false;
+        {
+            float v = tile[base + off[0]];
+            right[0] = !(v <= thr[0]);                 // NaN goes right, like the reference's `<=`
+        }
+        if constexpr (D > 1) {
+            int o = Sel<2, int>::get(off + 1, right);
+            float th = Sel<2, float>::get(thr + 1, right);
+            float v = tile[base + o];
+            right[1] = !(v <= th);
+        }
+        if constexpr (D > 2) {
+            int o = Sel<4, int>::get(off + 3, right);
+            float th = Sel<4, float>::get(thr + 3, right);
+            float v = tile[base + o];
+            right[2] = !(v <= th);
+        }
+        return Sel<NL, float>::get(pred, right);
     }
 };
 
@@ -125,13 +125,15 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     constexpr int SD = WB_STAGE_DWORDS(D);
     constexpr int G = GroupSize<D>::G;
     constexpr int S0 = 4;                                  // stages in phase A (multiple of G)
+    constexpr int SPAR_FROM = 16;                          // stage-parallel tail: from this stage on ...
+    constexpr int SPAR_MAX = 8;                            // ... when the wave has at most this many windows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const WbTile tile_d = a.tiles[blockIdx.x];
     const WbLevel L = a.levels[tile_d.level];
     const int b = blockIdx.y;
     const int pitch = a.lds_pitch, rows = a.lds_rows;
-    const int T = a.t_tile;
+    const int T = a.T;
 
     float *tile = reinterpret_cast<float *>(smem);
     const int tile_floats = a.C * rows * pitch;
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     // ---- phase B: dense re-packed survivors, stage segments [S0,2S0), [2S0,4S0), ...
     int t_begin = tA;
     while (t_begin < T && n_q > 0) {
+        if (t_begin >= SPAR_FROM && n_q <= SPAR_MAX) break;      // few windows left: flip to the tail
         int t_end = 2 * t_begin < T ? 2 * t_begin : T;
         int n_out = 0;
         for (int qb = 0; qb < n_q; qb += 64) {
@@ -283,7 +286,40 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         n_q = n_out;
         t_begin = t_end;
     }
-    if (t_begin < T) n_q = 0;   // every window of this wave died before the last tile-kernel stage
+
+    // ---- stage-parallel tail: one window at a time, lane i evaluates stage rs+i
+    for (int rs = t_begin; rs < T && n_q > 0; rs += 64) {
+        const int t = rs + lane;
+        const int nvalid = T - rs < 64 ? T - rs : 64;
+        Stage<D> st;                                             // this lane's own stage
+        st.load(stages + (size_t)(t < T ? t : T - 1) * SD);
+        int n_out = 0;
+        for (int i = 0; i < n_q; ++i) {
+            const uint2 e = queue[i];                            // same entry in every lane
+            const int pos = (int)e.x;
+            const int wbase = (pos >> 6) * pitch + (pos & 63);
+            const float p = st.eval(tile, wbase);
+            // Replay in stage order: lane k accumulates p_0 .. p_k one after the other -- the same
+            // additions in the same order as the reference's running `hs +=` -- so it ends up
+            // with the score the rejection test of stage rs+k sees.
+            float hk = __uint_as_float(e.y);
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), j));
+                if (lane >= j) hk = hk + pj;
+            }
+            const bool rej = (lane < nvalid) && (st.theta != -INFINITY) && !(hk >= st.theta);
+            const unsigned long long rmask = __ballot(rej);
+            const int last = rmask ? (int)__builtin_ctzll(rmask) : nvalid - 1;   // last stage entered
+            if (lane <= last) atomicAdd(&hist[t], 1u);
+            if (!rmask) {
+                float hl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hk), nvalid - 1));
+                if (lane == 0) queue[n_out] = make_uint2((uint32_t)pos, __float_as_uint(hl));   // n_out <= i
+                ++n_out;
+            }
+        }
+        n_q = n_out;
+    }
 
     // ---- epilogue: the wave queues now hold the windows alive after stage T-1.  One atomic per
     //      workgroup reserves their slots in one of the sharded output buffers.
@@ -294,7 +330,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         uint32_t total = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) total += wcnt[w];
-        wg_base = total ? atomicAdd(a.out_count + shard, total) : 0u;
+        wg_base = total ? atomicAdd(a.det_count + shard, total) : 0u;
     }
     uint32_t *al = a.alive + ((int64_t)b * a.n_levels + tile_d.level) * a.T;
     for (int t = tid; t < T; t += NT) {
@@ -305,10 +341,10 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     if (n_q > 0) {
         uint32_t o = wg_base;
         for (int w = 0; w < wave; ++w) o += wcnt[w];
-        WbDet *dst = a.out + (size_t)shard * a.out_cap;
+        WbDet *dst = a.det + (size_t)shard * a.det_cap;
         for (int i = lane; i < n_q; i += 64) {
             uint2 e = queue[i];
-            if (o + i < a.out_cap) {
+            if (o + i < a.det_cap) {
                 WbDet d;
                 d.image = b;
                 d.level = tile_d.level;
@@ -316,99 +352,6 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
                 d.c = (uint16_t)(c0 + ((int)e.x & 63));
                 d.score = __uint_as_float(e.y);
                 dst[o + i] = d;
-            }
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------
-// deep kernel: one wavefront per surviving window, one stage per lane, 64 stages per round.
-// grid = WB_DET_SHARDS * K workgroups of 4 waves; workgroup (s, k) walks entries of shard s.
-template <int D>
-__global__ __launch_bounds__(256) void cascade_deep_kernel(CascArgs a) {
-    constexpr int NI = WB_STAGE_NI(D), NL = WB_STAGE_NL(D), SD = WB_STAGE_DWORDS(D);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t shard = blockIdx.x % WB_DET_SHARDS;
-    const uint32_t k = blockIdx.x / WB_DET_SHARDS, K = gridDim.x / WB_DET_SHARDS;
-    uint32_t n_in = a.out_count[shard];
-    if (n_in > a.out_cap) n_in = a.out_cap;
-    const WbDet *src = a.out + (size_t)shard * a.out_cap;
-    const int T = a.T, t0 = a.t_tile;
-
-    for (uint32_t ei = k * 4 + wave; ei < n_in; ei += K * 4) {
-        const WbDet d = src[ei];                               // same address in every lane
-        const int level = __builtin_amdgcn_readfirstlane(d.level);
-        const int image = __builtin_amdgcn_readfirstlane(d.image);
-        const WbLevel L = a.levels[level];
-        const float *chn = a.chn + (int64_t)image * a.chn_stride + L.chn_off;
-        const int r = d.r, c = d.c;
-        float h = d.score;
-        bool dead = false;
-        uint32_t *al = a.alive + ((int64_t)image * a.n_levels + level) * T;
-
-        for (int rs = t0; rs < T && !dead; rs += 64) {
-            const int t = rs + lane;
-            const int nvalid = T - rs < 64 ? T - rs : 64;
-            // this lane's stage (lanes past T re-read the last record; their result is never used)
-            const int32_t *sp = a.stages_feat + (size_t)(t < T ? t : T - 1) * SD;
-            int feat[NI];
-            float thr[NI], pred[NL];
-#pragma unroll
-            for (int i = 0; i < NI; ++i) feat[i] = sp[i];
-#pragma unroll
-            for (int i = 0; i < NI; ++i) thr[i] = as_f(sp[NI + i]);
-#pragma unroll
-            for (int i = 0; i < NL; ++i) pred[i] = as_f(sp[2 * NI + i]);
-            float theta = as_f(sp[2 * NI + NL]);
-
-            int path = 0;
-#pragma unroll
-            for (int dd = 0; dd < D; ++dd) {
-                const int first = (1 << dd) - 1;
-                int f = feat[first];
-                float th = thr[first];
-#pragma unroll
-                for (int q = 1; q < (1 << dd); ++q) {          // per-lane select of the node on the path
-                    bool take = (path == q);
-                    f = take ? feat[first + q] : f;
-                    th = take ? thr[first + q] : th;
-                }
-                int fr = f & 255, fc = (f >> 8) & 255, ch = (f >> 16) & 255;
-                float v;
-                if (a.layout == WB_LAYOUT_PLANAR)
-                    v = chn[(int64_t)ch * L.u * L.vp + (int64_t)(r + fr) * L.vp + (c + fc)];
-                else
-                    v = chn[((int64_t)(r + fr) * L.v + (c + fc)) * a.C + ch];
-                path = 2 * path + ((v <= th) ? 0 : 1);
-            }
-            float p = pred[0];
-#pragma unroll
-            for (int q = 1; q < NL; ++q) p = (path == q) ? pred[q] : p;
-
-            // serial replay in stage order: h += p_t ; reject if theta_t != -inf and !(h >= theta_t)
-            int last = nvalid - 1;                                // last stage this window enters
-            for (int i = 0; i < nvalid; ++i) {                   // every lane computes the same h
-                float pi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), i));
-                float ti = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(theta), i));
-                h = h + pi;
-                int rej = (ti != -INFINITY && !(h >= ti)) ? 1 : 0;
-                if (__builtin_amdgcn_readfirstlane(rej)) {
-                    dead = true;
-                    last = i;
-                    break;
-                }
-            }
-            if (lane <= last) atomicAdd(al + t, 1u);              // windows entering stage t
-        }
-
-        if (!dead) {
-            uint32_t slot = 0;
-            if (lane == 0) slot = atomicAdd(a.det_count + shard, 1u);
-            slot = __builtin_amdgcn_readfirstlane(slot);
-            if (lane == 0 && slot < a.det_cap) {
-                WbDet o = d;
-                o.score = h;
-                a.det[(size_t)shard * a.det_cap + slot] = o;
             }
         }
     }
@@ -450,25 +393,17 @@ __global__ void boxes_kernel(const WbDet *det, int64_t n_det, const float *inv_s
 #define WB_CASC_CONFIGS(X) X(8, 4) X(4, 4) X(2, 4) X(1, 4) X(4, 8) X(2, 8) X(1, 8) X(2, 16) X(1, 16)
 
 template <int D>
-int launch_depth(hipStream_t st, dim3 grid, const CascArgs &a, int rpw, int waves, size_t lds, bool deep) {
-    bool launched = false;
+int launch_depth(hipStream_t st, dim3 grid, const CascArgs &a, int rpw, int waves, size_t lds) {
 #define WB_X(R, W)                                                                                          \
-    if (!launched && rpw == R && waves == W) {                                                              \
+    if (rpw == R && waves == W) {                                                                           \
         hipLaunchKernelGGL((cascade_tile_kernel<D, R, W>), grid, dim3(W * 64), lds, st, a, a.stages);       \
-        launched = true;                                                                                    \
+        WB_HIP_CHECK(hipGetLastError());                                                                    \
+        return WB_OK;                                                                                       \
     }
     WB_CASC_CONFIGS(WB_X)
 #undef WB_X
-    if (!launched) {
-        wb_set_error("cascade: no kernel for rows-per-wave %d x %d waves", rpw, waves);
-        return WB_ERR_INVALID;
-    }
-    if (deep) {
-        // fixed grid (no host read-back of the queue length): 16 workgroups per shard walk it
-        hipLaunchKernelGGL((cascade_deep_kernel<D>), dim3(WB_DET_SHARDS * 16), dim3(256), 0, st, a);
-    }
-    WB_HIP_CHECK(hipGetLastError());
-    return WB_OK;
+    wb_set_error("cascade: no kernel for rows-per-wave %d x %d waves", rpw, waves);
+    return WB_ERR_INVALID;
 }
 
 template <int D>
@@ -502,14 +437,12 @@ int wb_cascade_prepare(int depth, int rpw, int waves) {
 extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const float *chn, int64_t chn_stride,
                                  int layout, int batch, const WbLevel *levels, int n_levels,
                                  const WbTile *tiles, int n_tiles, WbDet *det, uint32_t *det_count,
-                                 uint32_t shard_capacity, WbDet *work, uint32_t *work_count, uint32_t *alive) {
+                                 uint32_t shard_capacity, uint32_t *alive) {
     WB_REQUIRE(model && chn && levels && tiles && det_count && alive, "wb_cascade_launch: null pointer");
     WB_REQUIRE(det || shard_capacity == 0, "wb_cascade_launch: det is null but capacity > 0");
     WB_REQUIRE(batch >= 1 && batch <= 65535, "wb_cascade_launch: batch %d out of range", batch);
     WB_REQUIRE(n_levels >= 1 && n_tiles >= 1, "wb_cascade_launch: empty launch");
     WB_REQUIRE(layout == WB_LAYOUT_PLANAR || layout == WB_LAYOUT_HWC, "wb_cascade_launch: bad layout %d", layout);
-    const bool deep = model->t_tile < model->n_stages;
-    WB_REQUIRE(!deep || (work && work_count), "wb_cascade_launch: this cascade needs the work queue (work, work_count)");
     CascArgs a;
     a.chn = chn;
     a.chn_stride = chn_stride;
@@ -518,17 +451,12 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const float
     a.tiles = tiles;
     a.n_levels = n_levels;
     a.stages = model->stages_dev;
-    a.stages_feat = model->stages_feat_dev;
     a.T = model->n_stages;
-    a.t_tile = model->t_tile;
     a.m = model->m;
     a.n = model->n;
     a.C = model->C;
     a.lds_rows = model->lds_rows;
     a.lds_pitch = model->lds_pitch;
-    a.out = deep ? work : det;
-    a.out_count = deep ? work_count : det_count;
-    a.out_cap = shard_capacity;
     a.det = det;
     a.det_count = det_count;
     a.det_cap = shard_capacity;
@@ -536,9 +464,9 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const float
     dim3 grid((unsigned)n_tiles, (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;
     switch (model->depth) {
-        case 1: return launch_depth<1>(st, grid, a, model->rpw, model->waves, (size_t)model->lds_bytes, deep);
-        case 2: return launch_depth<2>(st, grid, a, model->rpw, model->waves, (size_t)model->lds_bytes, deep);
-        case 3: return launch_depth<3>(st, grid, a, model->rpw, model->waves, (size_t)model->lds_bytes, deep);
+        case 1: return launch_depth<1>(st, grid, a, model->rpw, model->waves, (size_t)model->lds_bytes);
+        case 2: return launch_depth<2>(st, grid, a, model->rpw, model->waves, (size_t)model->lds_bytes);
+        case 3: return launch_depth<3>(st, grid, a, model->rpw, model->waves, (size_t)model->lds_bytes);
     }
     wb_set_error("wb_cascade_launch: model depth %d has no kernel", model->depth);
     return WB_ERR_UNSUPPORTED;

@@ -12,6 +12,8 @@
 //
 // Replaces reference channels.py:127-146 (per-level body of channel_pyramid), :40-52
 // (grad_hist), :16-21 (gradients), :55-64 (avg_pool_2), :78-90 (smooth).
+#include <stdlib.h>
+
 #include "wb_common.h"
 
 namespace {
@@ -28,6 +30,7 @@ struct ChanArgs {
     float *chn;
     int64_t chn_stride;
     double cs[4], sn[4];
+    float chi, clo;      // sin(pi/4) = chi + clo (two-float split) for the integer-gradient fast path
 };
 
 struct Tap {          // one axis of the bilinear resample (scipy NI_ZoomShift, order 1)
@@ -86,20 +89,49 @@ struct F4 {
 };
 
 // reference channels.py:78-83: nine-term sum in source order; numba promotes int64*float32 to
-// fp64, so the sum is fp64; "/16" and one rounding to fp32 on the store
-__device__ inline float smooth9(float a, float b, float c, float d, float e, float f, float g, float h, float i) {
-    double s = (double)a + 2.0 * (double)b;
-    s = s + (double)c;
-    s = s + 2.0 * (double)d;
-    s = s + 4.0 * (double)e;
-    s = s + 2.0 * (double)f;
-    s = s + (double)g;
-    s = s + 2.0 * (double)h;
-    s = s + (double)i;
-    return (float)(s / 16.0);
+// fp64, so the sum is fp64; "/16" and one rounding to fp32 on the store.
+// 2*x and 4*x are exact, so fma(2, b, acc) rounds exactly like acc + 2*b: same bits, half the ops.
+__device__ inline float smooth9(double a, double b, double c, double d, double e, double f, double g, double h, double i) {
+    double s = __builtin_fma(2.0, b, a);
+    s = s + c;
+    s = __builtin_fma(2.0, d, s);
+    s = __builtin_fma(4.0, e, s);
+    s = __builtin_fma(2.0, f, s);
+    s = s + g;
+    s = __builtin_fma(2.0, h, s);
+    s = s + i;
+    return (float)(s * 0.0625);
 }
 
-template <typename T, int S, int TU, int TV, bool SMOOTH>
+// grad_hist projection of one pixel: out[k] = | fp32( fp64(gx)*cos_k - fp64(gy)*sin_k ) |
+// (reference channels.py:47-52)
+__device__ inline void project_f64(float gx, float gy, const ChanArgs &a, float *out) {
+    double gxd = (double)gx, gyd = (double)gy;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float val = (float)(gxd * a.cs[k] - gyd * a.sn[k]);
+        out[k] = fmaxf(fabsf(val), 0.0f);
+    }
+}
+
+// Integer-valued gradients (uint8 images: |g| <= 1020) with the canonical 4-bin constants:
+// bit-identical to project_f64 for every (gx, gy) in [-1020, 1020]^2 -- checked exhaustively on
+// the device by wb_selftest_projection -- because
+//   k=0: gx*1 - gy*0 = gx;            k=2: gx*6.1e-17 - gy rounds to -gy unless gy == 0;
+//   k=1,3: the result depends only on d = |gx -/+ gy| (the 1-ulp difference between cos and sin
+//          of pi/4 is far below fp32 resolution unless d == 0) and fp32(d * sin(pi/4)) equals
+//          fma(d, chi, d*clo) for all d <= 2040.
+// The excluded lanes (gx != 0 and one of gy, gx-gy, gx+gy zero) take the fp64 path.
+__device__ inline void project_int(float gx, float gy, const ChanArgs &a, float *out) {
+    float d1 = fabsf(gx - gy), d3 = fabsf(gx + gy);
+    out[0] = fabsf(gx);
+    out[1] = __builtin_fmaf(d1, a.chi, d1 * a.clo);
+    out[2] = fabsf(gy);
+    out[3] = __builtin_fmaf(d3, a.chi, d3 * a.clo);
+    if (gx != 0.0f && (gy == 0.0f || d1 == 0.0f || d3 == 0.0f)) project_f64(gx, gy, a, out);
+}
+
+template <typename T, int S, int TU, int TV, bool SMOOTH, bool FAST>
 __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
     constexpr int HS = SMOOTH ? 1 : 0;
     constexpr int SU = TU + 2 * HS, SV = TV + 2 * HS;  // shrunk tile incl. smooth halo
@@ -122,35 +154,75 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
     const uint32_t *mm = a.minmax + ((int64_t)b * a.n_oct + L.oct) * 2;
     const double mn = Src<T>::lo(~mm[0]), mx = Src<T>::lo(mm[1]);   // mm[0] holds max(~key)
 
-    // ---- step 0: per-row / per-column resampling taps (coordinates clamped = 'reflect'
-    //      halo of convolve1d for a 1-pixel border)
     const int ry0 = S * (u0 - HS) - 1, rx0 = S * (v0 - HS) - 1;
-    for (int k = tid; k < RH + RW; k += 256) {
-        if (k < RH) {
-            int y = ry0 + k;
-            y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
-            rowtab[k] = make_tap(y, L.sy, L.src_h);
-        } else {
-            int x = rx0 + (k - RH);
-            x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
-            coltab[k - RH] = make_tap(x, L.sx, L.src_w);
+    // Levels at their octave's own size (scale 1: every level i=0 with even dims) resample with
+    // weights (1, 0): t = v*1*1 + 0 + 0 + 0 = v exactly, so the tile is a plain copy.
+    const bool ident = (L.src_h == L.nh) && (L.src_w == L.nw);
+    if (ident) {
+        constexpr int U = 4;
+        for (int p0 = tid; p0 < RH * RW; p0 += 256 * U) {
+            T v[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                int p = p0 + k * 256;
+                v[k] = T(0);
+                if (p < RH * RW) {
+                    int r = p / RW, q = p - r * RW;
+                    int y = ry0 + r, x = rx0 + q;
+                    y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
+                    x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
+                    v[k] = src[(int64_t)y * L.src_w + x];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+                if (p0 + k * 256 < RH * RW) R[p0 + k * 256] = (float)v[k];
         }
-    }
-    __syncthreads();
+    } else {
+        // ---- step 0: per-row / per-column resampling taps (coordinates clamped = 'reflect'
+        //      halo of convolve1d for a 1-pixel border)
+        for (int k = tid; k < RH + RW; k += 256) {
+            if (k < RH) {
+                int y = ry0 + k;
+                y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
+                rowtab[k] = make_tap(y, L.sy, L.src_h);
+            } else {
+                int x = rx0 + (k - RH);
+                x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
+                coltab[k - RH] = make_tap(x, L.sx, L.src_w);
+            }
+        }
+        __syncthreads();
 
-    // ---- step 1: bilinear resample into R (fp64, scipy tap order), cast back to the image dtype
-    for (int p = tid; p < RH * RW; p += 256) {
-        int k = p / RW, q = p - k * RW;
-        Tap tr = rowtab[k], tc = coltab[q];
-        const T *r0 = src + (int64_t)tr.i0 * L.src_w;
-        const T *r1 = src + (int64_t)tr.i1 * L.src_w;
-        double v00 = (double)r0[tc.i0], v01 = (double)r0[tc.i1];
-        double v10 = (double)r1[tc.i0], v11 = (double)r1[tc.i1];
-        double t = (v00 * tr.w0) * tc.w0;
-        t = t + (v01 * tr.w0) * tc.w1;
-        t = t + (v10 * tr.w1) * tc.w0;
-        t = t + (v11 * tr.w1) * tc.w1;
-        R[p] = Src<T>::finish(t, mn, mx);
+        // ---- step 1: bilinear resample into R (fp64, scipy tap order), cast back to the image
+        //      dtype.  U pixels per pass: their 4*U source loads are issued before any arithmetic.
+        constexpr int U = 4;
+        for (int p0 = tid; p0 < RH * RW; p0 += 256 * U) {
+            T v00[U], v01[U], v10[U], v11[U];
+            double wr0[U], wr1[U], wc0[U], wc1[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                int p = p0 + k * 256;
+                p = p < RH * RW ? p : RH * RW - 1;
+                int r = p / RW, q = p - r * RW;
+                Tap tr = rowtab[r], tc = coltab[q];
+                const T *r0 = src + (int64_t)tr.i0 * L.src_w;
+                const T *r1 = src + (int64_t)tr.i1 * L.src_w;
+                v00[k] = r0[tc.i0];
+                v01[k] = r0[tc.i1];
+                v10[k] = r1[tc.i0];
+                v11[k] = r1[tc.i1];
+                wr0[k] = tr.w0; wr1[k] = tr.w1; wc0[k] = tc.w0; wc1[k] = tc.w1;
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                double t = ((double)v00[k] * wr0[k]) * wc0[k];
+                t = t + ((double)v01[k] * wr0[k]) * wc1[k];
+                t = t + ((double)v10[k] * wr1[k]) * wc0[k];
+                t = t + ((double)v11[k] * wr1[k]) * wc1[k];
+                if (p0 + k * 256 < RH * RW) R[p0 + k * 256] = Src<T>::finish(t, mn, mx);
+            }
+        }
     }
     __syncthreads();
 
@@ -181,12 +253,10 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
             for (int x = 0; x < S; ++x) {
                 float gx = Src<T>::dpass(hc[y][x], hc[y][x + 2]);
                 float gy = Src<T>::dpass(hr[y][x], hr[y + 2][x]);
-                double gxd = (double)gx, gyd = (double)gy;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float val = (float)(gxd * a.cs[k] - gyd * a.sn[k]);
-                    ch[y][x][k] = fmaxf(fabsf(val), 0.0f);
-                }
+                if constexpr (FAST)
+                    project_int(gx, gy, a, ch[y][x]);
+                else
+                    project_f64(gx, gy, a, ch[y][x]);
             }
 
         float o[4];
@@ -211,64 +281,108 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
     }
     __syncthreads();
 
-    // ---- step 3: 3x3 binomial smooth (fp64 sum in source order, /16, one rounding), border = 0
+    // ---- step 3: 3x3 binomial smooth (fp64 sum in source order, /16, one rounding), border = 0.
+    //      Each thread owns RPT vertically adjacent outputs of one column, so every shrunk value
+    //      it needs is read and widened to fp64 once for up to three output rows.
+    constexpr int RPT = TU * TV / 256;
+    static_assert(TU * TV % 256 == 0 && 256 % TV == 0, "tile must split into whole thread strips");
     float *out = a.chn + (int64_t)b * a.chn_stride + L.chn_off;
     const int64_t plane = (int64_t)L.u * L.vp;
-    for (int p = tid; p < TU * TV; p += 256) {
-        int i = p / TV, j = p - i * TV;
-        int su = u0 + i, sv = v0 + j;
-        if (su >= L.u || sv >= L.v) continue;
-        float o[4];
-        if constexpr (SMOOTH) {
-            if (su == 0 || sv == 0 || su == L.u - 1 || sv == L.v - 1) {
-                o[0] = o[1] = o[2] = o[3] = 0.0f;
-            } else {
-                const F4 *c = &Sh[(i + 1) * SV + (j + 1)];
-                F4 n00 = c[-SV - 1], n01 = c[-SV], n02 = c[-SV + 1];
-                F4 n10 = c[-1], n11 = c[0], n12 = c[1];
-                F4 n20 = c[SV - 1], n21 = c[SV], n22 = c[SV + 1];
-                o[0] = smooth9(n00.x, n01.x, n02.x, n10.x, n11.x, n12.x, n20.x, n21.x, n22.x);
-                o[1] = smooth9(n00.y, n01.y, n02.y, n10.y, n11.y, n12.y, n20.y, n21.y, n22.y);
-                o[2] = smooth9(n00.z, n01.z, n02.z, n10.z, n11.z, n12.z, n20.z, n21.z, n22.z);
-                o[3] = smooth9(n00.w, n01.w, n02.w, n10.w, n11.w, n12.w, n20.w, n21.w, n22.w);
+    const int j = tid % TV, i0 = (tid / TV) * RPT;
+    const int sv = v0 + j;
+    float o[RPT][4];
+    if constexpr (SMOOTH) {
+        double w[RPT + 2][3][4];
+#pragma unroll
+        for (int y = 0; y < RPT + 2; ++y)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                F4 c = Sh[(i0 + y) * SV + (j + x)];
+                w[y][x][0] = (double)c.x; w[y][x][1] = (double)c.y; w[y][x][2] = (double)c.z; w[y][x][3] = (double)c.w;
             }
-        } else {
-            F4 c = Sh[p];
-            o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
+#pragma unroll
+        for (int y = 0; y < RPT; ++y)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                o[y][k] = smooth9(w[y][0][k], w[y][1][k], w[y][2][k], w[y + 1][0][k], w[y + 1][1][k], w[y + 1][2][k],
+                                  w[y + 2][0][k], w[y + 2][1][k], w[y + 2][2][k]);
+    } else {
+#pragma unroll
+        for (int y = 0; y < RPT; ++y) {
+            F4 c = Sh[(i0 + y) * SV + j];
+            o[y][0] = c.x; o[y][1] = c.y; o[y][2] = c.z; o[y][3] = c.w;
         }
+    }
+#pragma unroll
+    for (int y = 0; y < RPT; ++y) {
+        const int su = u0 + i0 + y;
+        if (su >= L.u || sv >= L.v) continue;
+        if (SMOOTH && (su == 0 || sv == 0 || su == L.u - 1 || sv == L.v - 1)) o[y][0] = o[y][1] = o[y][2] = o[y][3] = 0.0f;
         if (a.layout == WB_LAYOUT_HWC) {
             float4 *dst = reinterpret_cast<float4 *>(out + ((int64_t)su * L.v + sv) * 4);
-            *dst = make_float4(o[0], o[1], o[2], o[3]);
+            *dst = make_float4(o[y][0], o[y][1], o[y][2], o[y][3]);
         } else {
             float *dst = out + (int64_t)su * L.vp + sv;
-            dst[0] = o[0];
-            dst[plane] = o[1];
-            dst[2 * plane] = o[2];
-            dst[3 * plane] = o[3];
+            dst[0] = o[y][0];
+            dst[plane] = o[y][1];
+            dst[2 * plane] = o[y][2];
+            dst[3 * plane] = o[y][3];
         }
     }
 }
 
-template <typename T, int S, int TU, int TV>
-void launch_variant(hipStream_t st, dim3 grid, const ChanArgs &a, bool smooth) {
-    if (smooth)
-        hipLaunchKernelGGL((channels_kernel<T, S, TU, TV, true>), grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((channels_kernel<T, S, TU, TV, false>), grid, dim3(256), 0, st, a);
+// Exhaustive device check of project_int against project_f64 over [-1020, 1020]^2.
+__global__ void selftest_projection_kernel(ChanArgs a, uint32_t *mismatches) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = 2041;
+    if (i >= n * n) return;
+    float gx = (float)(i / n - 1020), gy = (float)(i % n - 1020);
+    float f[4], r[4];
+    project_int(gx, gy, a, f);
+    project_f64(gx, gy, a, r);
+    for (int k = 0; k < 4; ++k)
+        if (__float_as_uint(f[k]) != __float_as_uint(r[k])) atomicAdd(mismatches, 1u);
 }
 
-template <typename T>
+template <typename T, int S, int TU, int TV, bool FAST>
+void launch_variant(hipStream_t st, dim3 grid, const ChanArgs &a, bool smooth) {
+    if (smooth)
+        hipLaunchKernelGGL((channels_kernel<T, S, TU, TV, true, FAST>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((channels_kernel<T, S, TU, TV, false, FAST>), grid, dim3(256), 0, st, a);
+}
+
+template <typename T, bool FAST>
 int launch_dtype(hipStream_t st, dim3 grid, const ChanArgs &a, int shrink, bool smooth) {
     switch (shrink) {
-        case 1: launch_variant<T, 1, 16, 64>(st, grid, a, smooth); break;
-        case 2: launch_variant<T, 2, 16, 64>(st, grid, a, smooth); break;
-        case 4: launch_variant<T, 4, 8, 32>(st, grid, a, smooth); break;
+        case 1: launch_variant<T, 1, 16, 64, FAST>(st, grid, a, smooth); break;
+        case 2: launch_variant<T, 2, 16, 64, FAST>(st, grid, a, smooth); break;
+        case 4: launch_variant<T, 4, 8, 32, FAST>(st, grid, a, smooth); break;
         default:
             wb_set_error("wb_channels_launch: shrink=%d unsupported (1, 2; 4 as an extension)", shrink);
             return WB_ERR_UNSUPPORTED;
     }
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;
+}
+
+// the canonical constants np.cos/np.sin(np.linspace(0, pi, 5)[:-1]) the integer fast path is proven for
+const double kCanonCs[4] = {1.0, 0x1.6a09e667f3bcdp-1, 0x1.1a62633145c07p-54, -0x1.6a09e667f3bccp-1};
+const double kCanonSn[4] = {0.0, 0x1.6a09e667f3bccp-1, 1.0, 0x1.6a09e667f3bcdp-1};
+
+bool canonical_constants(const double *cs_sn) {
+    for (int k = 0; k < 4; ++k)
+        if (cs_sn[k] != kCanonCs[k] || cs_sn[4 + k] != kCanonSn[k]) return false;
+    return true;
+}
+
+void set_constants(ChanArgs &a, const double *cs_sn) {
+    for (int k = 0; k < 4; ++k) {
+        a.cs[k] = cs_sn[k];
+        a.sn[k] = cs_sn[4 + k];
+    }
+    a.chi = (float)cs_sn[5];
+    a.clo = (float)(cs_sn[5] - (double)a.chi);
 }
 
 }  // namespace
@@ -311,14 +425,31 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
     a.layout = layout;
     a.chn = chn;
     a.chn_stride = chn_stride;
-    for (int k = 0; k < 4; ++k) {
-        a.cs[k] = cs_sn[k];
-        a.sn[k] = cs_sn[4 + k];
-    }
+    set_constants(a, cs_sn);
     dim3 grid((unsigned)n_tiles, (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == WB_DTYPE_U8) return launch_dtype<uint8_t>(st, grid, a, shrink, smooth != 0);
-    if (dtype == WB_DTYPE_F32) return launch_dtype<float>(st, grid, a, shrink, smooth != 0);
+    if (dtype == WB_DTYPE_U8) {
+        // integer gradients + canonical constants: exact fp32 projection (see project_int)
+        static const bool no_fast = getenv("WB_CHAN_NO_FAST") != nullptr;
+        if (canonical_constants(cs_sn) && !no_fast) return launch_dtype<uint8_t, true>(st, grid, a, shrink, smooth != 0);
+        return launch_dtype<uint8_t, false>(st, grid, a, shrink, smooth != 0);
+    }
+    if (dtype == WB_DTYPE_F32) return launch_dtype<float, false>(st, grid, a, shrink, smooth != 0);
     wb_set_error("wb_channels_launch: unsupported dtype %d (uint8 and float32 images only)", dtype);
     return WB_ERR_UNSUPPORTED;
+}
+
+extern "C" int wb_selftest_projection(void *stream, uint32_t *mismatches) {
+    WB_REQUIRE(mismatches, "wb_selftest_projection: null pointer");
+    ChanArgs a = {};
+    double cs_sn[8];
+    for (int k = 0; k < 4; ++k) {
+        cs_sn[k] = kCanonCs[k];
+        cs_sn[4 + k] = kCanonSn[k];
+    }
+    set_constants(a, cs_sn);
+    const int n = 2041 * 2041;
+    hipLaunchKernelGGL(selftest_projection_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, mismatches);
+    WB_HIP_CHECK(hipGetLastError());
+    return WB_OK;
 }

@@ -67,7 +67,5 @@ struct WbModel {
     int lds_pitch;    // (WB_CASC_TC + n - 1) rounded up to 4 floats
     int lds_bytes;
     int stage_dwords;
-    int t_tile;                 // stages run by the tile kernel; the rest go to the deep kernel
-    int32_t *stages_dev;        // (n_stages + G) records with LDS float offsets (tile kernel)
-    int32_t *stages_feat_dev;   // n_stages records with packed (row | col<<8 | channel<<16) (deep kernel)
+    int32_t *stages_dev;        // (n_stages + G) stage records with LDS float offsets
 };

@@ -85,7 +85,6 @@ class DeviceCascade:
         self.n_stages, self.depth = info.n_stages, info.depth
         self.m, self.n, self.C = info.m, info.n, info.C
         self.tile_rows, self.tile_cols, self.lds_bytes = info.tile_rows, info.tile_cols, info.lds_bytes
-        self.handoff_stage = info.handoff_stage
 
     def __del__(self):
         try:
@@ -179,12 +178,11 @@ class PyramidEngine:
             self.minmax[:, :, 1] = int(hi)
 
     def _alloc_det(self):
-        """Detection buffer and the tile->deep work queue (same sharded layout); det_capacity is
-        the total record capacity, split evenly over the shards."""
+        """Sharded detection buffer; det_capacity is the total record capacity, split evenly over
+        the shards."""
         cap = max(16, -(-self.det_capacity // nat.WB_DET_SHARDS))
         self.det_capacity = cap * nat.WB_DET_SHARDS
         self.detb = DetBuffer(cap, self.dev)
-        self.workb = DetBuffer(cap, self.dev)
         self.det_buf = self.detb.buf
 
     # ------------------------------------------------------------------ input
@@ -248,8 +246,7 @@ class PyramidEngine:
         nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.chn), self.chn_stride,
                                              self.layout, self.batch, nat.ptr(self.levels), self.plan.n_levels,
                                              nat.ptr(stt["tiles"]), stt["n_tiles"], nat.ptr(self.detb.recs),
-                                             nat.ptr(self.detb.counts), self.detb.cap, nat.ptr(self.workb.recs),
-                                             nat.ptr(self.workb.counts), nat.ptr(stt["alive"])),
+                                             nat.ptr(self.detb.counts), self.detb.cap, nat.ptr(stt["alive"])),
                   "wb_cascade_launch")
         return stt
 
@@ -257,7 +254,6 @@ class PyramidEngine:
         """Zero the counters and scan every level of every image with cascade `dm`."""
         stt = self._casc_state(dm)
         self.detb.zero()
-        self.workb.zero()
         stt["alive"].zero_()
         return self.launch_cascade(dm)
 
@@ -284,10 +280,10 @@ class PyramidEngine:
 
     # ------------------------------------------------------------------ results
     def ensure_capacity(self, dm):
-        """Re-run the cascade with larger buffers if a shard of the detection buffer or of the
-        work queue overflowed in the last scan.  Returns the number of detections."""
+        """Re-run the cascade with a larger buffer if a shard of the detection buffer overflowed
+        in the last scan.  Returns the number of detections."""
         while True:
-            need = max(self.detb.max_count(), self.workb.max_count())
+            need = self.detb.max_count()
             if need <= self.detb.cap:
                 return int(self.detb.counts.sum().item())
             self.det_capacity = (int(need * 1.5) + 16) * nat.WB_DET_SHARDS

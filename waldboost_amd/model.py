@@ -235,7 +235,6 @@ class _SingleLevel:
         self.levels = torch.from_numpy(t.view(np.uint8).copy()).to(self.dev)
         self.X = torch.empty((max(u * v * C, 1),), dtype=torch.float32, device=self.dev)
         self.detb = _engine.DetBuffer(1 << 10, self.dev)
-        self.workb = _engine.DetBuffer(1 << 10, self.dev)
         self._tiles = {}
 
     def load(self, X):
@@ -257,19 +256,16 @@ class _SingleLevel:
         alive = torch.zeros((1, 1, max(T, 1)), dtype=torch.int32, device=self.dev)
         while True:
             self.detb.zero()
-            self.workb.zero()
             alive.zero_()
             if n_tiles:
                 nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.X), 0, nat.WB_LAYOUT_HWC,
                                                      1, nat.ptr(self.levels), 1, nat.ptr(tiles), n_tiles,
                                                      nat.ptr(self.detb.recs), nat.ptr(self.detb.counts), self.detb.cap,
-                                                     nat.ptr(self.workb.recs), nat.ptr(self.workb.counts),
                                                      nat.ptr(alive)), "wb_cascade_launch")
-            need = max(self.detb.max_count(), self.workb.max_count())
+            need = self.detb.max_count()
             if need <= self.detb.cap:
                 break
             self.detb = _engine.DetBuffer(int(need * 1.5) + 16, self.dev)
-            self.workb = _engine.DetBuffer(int(need * 1.5) + 16, self.dev)
         n = int(self.detb.counts.sum().item())
         return n, alive[0, 0, :T].cpu().numpy().astype(np.int64)
 
