@@ -45,8 +45,9 @@ extern "C" {
 #define WB_DTYPE_U8 0
 #define WB_DTYPE_F32 1
 
-#define WB_LAYOUT_PLANAR 0 /* [C][u][vp], vp = v rounded up to 4 floats (kernel-internal) */
-#define WB_LAYOUT_HWC 1    /* [u][v][C], the layout channel_pyramid hands to callers     */
+/* Channel images are [u][v][C] float32 everywhere (the layout channel_pyramid hands to callers):
+ * with C = 4 a pixel is one aligned float4, so the channel kernel stores 16 B per lane and a
+ * cascade tile row is one contiguous run in HBM. */
 
 #define WB_MAX_OCTAVES 24
 
@@ -66,7 +67,7 @@ typedef struct WbLevel {
     int32_t nw;
     int32_t u;        /* channel image size = nh/shrink, nw/shrink                  */
     int32_t v;
-    int32_t vp;       /* planar row pitch in floats (v rounded up to 4)             */
+    int32_t vp;       /* reserved (= v)                                             */
     int64_t src_off;  /* element offset of the octave in the per-image octave buffer;
                          octave 0 lives in the image buffer itself (src_off unused) */
     int64_t chn_off;  /* float offset of this level in the per-image channel buffer */
@@ -124,13 +125,12 @@ int wb_octaves_launch(void *stream, const void *img, int dtype, int batch, int H
  * channels (fp64 projection) -> shrink -> 3x3 smooth, fused per tile.
  *   levels   dev  WbLevel[n_levels];  tiles dev WbTile[n_tiles] (tile = wb_channels_tile)
  *   cs_sn    HOST double[8]: cos(theta_k), k=0..3 then sin(theta_k) (channels.py:43-46)
- *   chn      dev  float, image b at chn + b*chn_stride, level l at + levels[l].chn_off
- *   layout   WB_LAYOUT_PLANAR or WB_LAYOUT_HWC (HWC uses pitch v, planar pitch vp) */
+ *   chn      dev  float [u][v][4] per level, image b at chn + b*chn_stride, level l at
+ *                 + levels[l].chn_off (16-byte aligned) */
 int wb_channels_launch(void *stream, const void *img, int64_t img_stride, const void *oct,
                        int64_t oct_stride, int dtype, int batch, const WbLevel *levels, int n_levels,
                        const WbTile *tiles, int n_tiles, const uint32_t *minmax, int n_oct,
-                       int shrink, int smooth, const double *cs_sn, float *chn, int64_t chn_stride,
-                       int layout);
+                       int shrink, int smooth, const double *cs_sn, float *chn, int64_t chn_stride);
 
 /* Build the device-side cascade from the reference's tree arrays (all HOST pointers).
  *   node_off  int32[n_stages+1]  first node of each stage's tree in the flat arrays
@@ -147,19 +147,25 @@ int wb_model_destroy(WbModel *model);
 int wb_model_info(const WbModel *model, WbModelInfo *info);
 
 /* Dense sliding-window cascade over all levels of all images.
- *   chn/layout    as written by wb_channels_launch (or caller-provided HWC arrays)
+ *   chn           [u][v][C] per level as written by wb_channels_launch (or caller-provided)
  *   tiles         dev WbTile[n_tiles]: tiles of tile_rows x tile_cols WINDOWS over the
  *                 (u-m) x (v-n) window grid of each level
  *   det           dev WbDet[WB_DET_SHARDS][shard_capacity]; det_count dev uint32[WB_DET_SHARDS]:
  *                 survivors per shard (a count may exceed shard_capacity: the records beyond it
  *                 are dropped, the count stays exact -- grow the buffer and launch again)
- *   alive         dev uint32 [batch][n_levels][n_stages]: windows entering each stage
- * det_count and alive are ACCUMULATED into: the caller zeroes them.  Record order
- * is unspecified; sort by (image, level, r, c) to obtain the reference order. */
+ *   tile_csr      dev int32[n_levels + 1 + n_tiles]: for each level the range [start, end) into
+ *                 the trailing list of tile indices that belong to it (tiles grouped by level)
+ *   tile_hist     dev uint32 [batch][n_tiles][n_stages] scratch: per-workgroup alive counts,
+ *                 fully overwritten (no zeroing needed)
+ *   alive         dev uint32 [batch][n_levels][n_stages]: windows entering each stage, summed
+ *                 over the level's tiles by a small follow-up kernel; overwritten
+ * det_count is ACCUMULATED into: the caller zeroes it.  Record order is unspecified; sort by
+ * (image, level, r, c) to obtain the reference order. */
 int wb_cascade_launch(void *stream, const WbModel *model, const float *chn, int64_t chn_stride,
-                      int layout, int batch, const WbLevel *levels, int n_levels,
-                      const WbTile *tiles, int n_tiles, WbDet *det, uint32_t *det_count,
-                      uint32_t shard_capacity, uint32_t *alive);
+                      int batch, const WbLevel *levels, int n_levels,
+                      const WbTile *tiles, const int32_t *tile_csr, int n_tiles, WbDet *det,
+                      uint32_t *det_count, uint32_t shard_capacity, uint32_t *tile_hist,
+                      uint32_t *alive);
 
 /* One tree evaluated at explicit window origins (rs[i], cs[i]) of an HWC channel image
  * X[u][v][C]; out[i] = prediction of the leaf reached (training.py:84-96). Tree arrays

@@ -13,7 +13,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libwaldboost_hip.so")
 
 WB_DTYPE_U8, WB_DTYPE_F32 = 0, 1
-WB_LAYOUT_PLANAR, WB_LAYOUT_HWC = 0, 1
 WB_ERR_INVALID, WB_ERR_HIP, WB_ERR_UNSUPPORTED = -1, -2, -3
 WB_DET_SHARDS = 64
 
@@ -41,12 +40,12 @@ SYMBOLS = {
     "wb_octaves_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, C.c_int64,
                                     C.POINTER(C.c_int64), C.c_int, _P]),
     "wb_channels_launch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int,
-                                     _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P, C.c_int64, C.c_int]),
+                                     _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P, C.c_int64]),
     "wb_model_create": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "wb_model_destroy": (C.c_int, [_P]),
     "wb_model_info": (C.c_int, [_P, C.POINTER(WbModelInfo)]),
-    "wb_cascade_launch": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P,
-                                    C.c_uint32, _P]),
+    "wb_cascade_launch": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P,
+                                    C.c_uint32, _P, _P]),
     "wb_tree_eval_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P, _P, _P, _P, _P,
                                       C.c_int, _P]),
     "wb_boxes_launch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int, C.c_int, _P, _P]),

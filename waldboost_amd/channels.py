@@ -28,7 +28,7 @@ def grad_hist(image, n_bins=4, full=False, bias=0):
     H, W = img.shape
     if H < 1 or W < 1:
         return np.empty((H, W, 4), np.float32)
-    eng = _engine.get_engine(H, W, np.float32, 1, 1, 0, 1, nat.WB_LAYOUT_HWC, exact_single=True)
+    eng = _engine.get_engine(H, W, np.float32, 1, 1, 0, 1, exact_single=True)
     eng.load_images(img)
     eng.run_channels()
     return eng.read_level(0, 0)
@@ -70,7 +70,7 @@ def channel_pyramid(image, channel_opts):
     _validate_image(image)
     shrink, n_per_oct, smooth = read_opts(channel_opts)
     H, W = image.shape
-    eng = _engine.get_engine(H, W, image.dtype, shrink, n_per_oct, smooth, 1, nat.WB_LAYOUT_HWC)
+    eng = _engine.get_engine(H, W, image.dtype, shrink, n_per_oct, smooth, 1)
     if eng.plan.n_levels == 0:
         return
     eng.load_images(image)

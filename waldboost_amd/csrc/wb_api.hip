@@ -110,7 +110,7 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
     M->m = m;
     M->n = n;
     M->C = C;
-    M->lds_pitch = ((WB_CASC_TC + n - 1) + 3) & ~3;
+    M->lds_pitch = WB_CASC_TC + n;      // tile row (64 + n - 1 pixels) + one pad column (spare slot of the tile load)
     // tile = (rpw * waves) x 64 windows; WB_CASC_RPW / WB_CASC_WAVES override the default for tuning
     const int budget = 80 * 1024;
     int rpw = 4, waves = 8;

@@ -27,6 +27,8 @@
 //
 // Scores are accumulated in fp32 strictly in stage order and compared with `>=`, so they are
 // bit-identical to the reference's `hs += ...; mask = hs >= theta`.
+#include <stdlib.h>
+
 #include "wb_common.h"
 
 namespace {
@@ -34,7 +36,6 @@ namespace {
 struct CascArgs {
     const float *chn;
     int64_t chn_stride;
-    int layout;
     const WbLevel *levels;
     const WbTile *tiles;
     int n_levels;
@@ -44,10 +45,15 @@ struct CascArgs {
     WbDet *det;
     uint32_t *det_count;
     uint32_t det_cap;           // per shard
-    uint32_t *alive;
+    uint32_t *tile_hist;        // [batch][n_tiles][T] scratch: each workgroup's per-stage alive counts
+    uint32_t *alive;            // [batch][n_levels][T] written by the reduction kernel
+    const int32_t *tile_csr;    // [n_levels + 1] starts, then [n_tiles] tile indices grouped by level
+    int n_tiles;
+    int dbg;                    // diagnostics (WB_CASC_DBG): 1 = skip the tile load, 2 = stop after the load
 };
 
 __device__ inline float as_f(int32_t x) { return __int_as_float(x); }
+
 
 // a[path] for the root-to-node path bits[0..] (false = left, true = right), first decision first
 template <int N, typename V> struct Sel {
@@ -125,8 +131,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     constexpr int SD = WB_STAGE_DWORDS(D);
     constexpr int G = GroupSize<D>::G;
     constexpr int S0 = 4;                                  // stages in phase A (multiple of G)
-    constexpr int SPAR_FROM = 16;                          // stage-parallel tail: from this stage on ...
-    constexpr int SPAR_MAX = 8;                            // ... when the wave has at most this many windows
+    constexpr int SPAR_FROM = 16, SPAR_MAX = 8;            // when a wave flips to the stage-parallel tail (see run_segments)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const WbTile tile_d = a.tiles[blockIdx.x];
@@ -148,37 +153,45 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
 
     // ---- stage the channel block into LDS (planar [C][rows][pitch])
     const float *chn = a.chn + (int64_t)b * a.chn_stride + L.chn_off;
-    if (a.layout == WB_LAYOUT_PLANAR) {
-        // The LDS tile is one linear array of float4 (pitch is a multiple of 4), element e =
-        // (ch*rows + row)*p4 + q.  Each thread owns elements tid, tid+NT, ...; U of them are
-        // loaded back to back before the first LDS store so that U HBM/L2 requests per lane are
-        // in flight (a load-store-load-store loop serialises on memory latency).
+    if (a.dbg & 1) {
+    } else if (a.C == 4) {
+        // Channels live in HBM as one float4 per pixel ([u][v][4]): a tile row is ONE contiguous
+        // run of (64+n-1)*16 bytes.  Each thread loads U pixels back to back (straight-line code:
+        // a branch around a load or a store makes the compiler sink each load next to its use and
+        // wait for it alone), then scatters each pixel's 4 values to the 4 LDS planes (consecutive
+        // lanes -> consecutive LDS addresses in every plane).  Out-of-level pixels receive some
+        // other valid pixel of the level -- no existing window reads them -- and elements past
+        // the end of the tile land in a spare slot behind each plane's last row.
         constexpr int U = 8;
-        const int p4 = pitch >> 2;
-        const int total4 = a.C * rows * p4;
-        const int64_t plane = (int64_t)L.u * L.vp;
-        const int drow = NT / p4, dq = NT - drow * p4;
-        int rowall = tid / p4, q = tid - rowall * p4;       // rowall = ch*rows + row
-        int ch = rowall / rows, row = rowall - ch * rows;
-        float4 *tile4 = reinterpret_cast<float4 *>(tile);
-        for (int e0 = tid; e0 < total4; e0 += NT * U) {
+        const int ncol = WB_CASC_TC + a.n - 1;               // pixels per tile row
+        const int total = rows * ncol;
+        const uint32_t m_ncol = 0xFFFFFFFFu / (uint32_t)ncol + 1u;   // exact e / ncol for e < 2^16
+        const float4 *src = reinterpret_cast<const float4 *>(chn);
+        const int plane = rows * pitch;
+        for (int e0 = tid; e0 < total; e0 += NT * U) {
             float4 v[U];
+            int dst[U];
 #pragma unroll
             for (int k = 0; k < U; ++k) {
-                v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                int gr = r0 + row, gc = c0 + 4 * q;
-                if (e0 + k * NT < total4 && gr < L.u && gc < L.vp)
-                    v[k] = *reinterpret_cast<const float4 *>(chn + ch * plane + (int64_t)gr * L.vp + gc);
-                row += drow;
-                q += dq;
-                if (q >= p4) { q -= p4; ++row; }
-                while (row >= rows) { row -= rows; ++ch; }
+                uint32_t e = (uint32_t)(e0 + k * NT);
+                const bool in = e < (uint32_t)total;
+                e = in ? e : (uint32_t)total - 1u;
+                uint32_t row = __umulhi(e, m_ncol), col = e - row * (uint32_t)ncol;
+                int gr = r0 + (int)row, gc = c0 + (int)col;
+                gr = gr < L.u ? gr : L.u - 1;
+                gc = gc < L.v ? gc : L.v - 1;
+                v[k] = src[(int64_t)gr * L.v + gc];
+                dst[k] = in ? (int)(row * (uint32_t)pitch + col) : plane - 1;   // last pad column of the last row: never read
             }
 #pragma unroll
-            for (int k = 0; k < U; ++k)
-                if (e0 + k * NT < total4) tile4[e0 + k * NT] = v[k];
+            for (int k = 0; k < U; ++k) {
+                tile[dst[k]] = v[k].x;
+                tile[dst[k] + plane] = v[k].y;
+                tile[dst[k] + 2 * plane] = v[k].z;
+                tile[dst[k] + 3 * plane] = v[k].w;
+            }
         }
-    } else {  // HWC arrays handed in by a caller (Model.predict_on_image on host data)
+    } else {  // any other channel count (caller-supplied arrays): generic element loop
         const int total = a.C * rows * pitch;
         for (int idx = tid; idx < total; idx += NT) {
             int ch = idx % a.C;
@@ -191,6 +204,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         }
     }
     __syncthreads();
+    if (a.dbg & 2) return;
 
     // ---- phase A: RPW windows per lane through stages [0, S0)
     float hs[RPW];
@@ -243,49 +257,90 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         n_q += cnt;
     }
 
+    if (a.dbg & 4) return;
     // ---- phase B: dense re-packed survivors, stage segments [S0,2S0), [2S0,4S0), ...
     int t_begin = tA;
-    while (t_begin < T && n_q > 0) {
-        if (t_begin >= SPAR_FROM && n_q <= SPAR_MAX) break;      // few windows left: flip to the tail
-        int t_end = 2 * t_begin < T ? 2 * t_begin : T;
-        int n_out = 0;
-        for (int qb = 0; qb < n_q; qb += 64) {
-            int i = qb + lane;
-            bool alive = i < n_q;
-            uint2 e = alive ? queue[i] : make_uint2(0u, 0u);
-            int pos = (int)e.x;
-            float h = __uint_as_float(e.y);
-            int wbase = (pos >> 6) * pitch + (pos & 63);
-            for (int t = t_begin; t < t_end; t += G) {
-                if (__ballot(alive) == 0ull) break;
-                Stage<D> st[G];
-                const int32_t *sp = stages + (size_t)__builtin_amdgcn_readfirstlane(t) * SD;
+    // wave-synchronous segments from t_begin up to (at most) t_stop, compacting after each
+    auto run_segments = [&](int t_stop) {
+        while (t_begin < t_stop && n_q > 0) {
+            // few windows left: the stage-parallel tail is cheaper than walking groups of G
+            if ((t_begin >= 32 && n_q <= SPAR_MAX) || (t_begin >= SPAR_FROM && n_q <= 2)) break;
+            int t_end = 2 * t_begin < t_stop ? 2 * t_begin : t_stop;
+            int n_out = 0;
+            for (int qb = 0; qb < n_q; qb += 64) {
+                int i = qb + lane;
+                bool alive = i < n_q;
+                uint2 e = alive ? queue[i] : make_uint2(0u, 0u);
+                int pos = (int)e.x;
+                float h = __uint_as_float(e.y);
+                int wbase = (pos >> 6) * pitch + (pos & 63);
+                for (int t = t_begin; t < t_end; t += G) {
+                    if (__ballot(alive) == 0ull) break;
+                    Stage<D> st[G];
+                    const int32_t *sp = stages + (size_t)__builtin_amdgcn_readfirstlane(t) * SD;
 #pragma unroll
-                for (int g = 0; g < G; ++g) st[g].load(sp + g * SD);
-                float p[G];
+                    for (int g = 0; g < G; ++g) st[g].load(sp + g * SD);
+                    float p[G];
 #pragma unroll
-                for (int g = 0; g < G; ++g) p[g] = st[g].eval(tile, wbase);
+                    for (int g = 0; g < G; ++g) p[g] = st[g].eval(tile, wbase);
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    if (t + g >= t_end) break;
-                    int cnt = __popcll(__ballot(alive));
-                    if (cnt && lane == 0) atomicAdd(&hist[t + g], (uint32_t)cnt);
-                    float h2 = h + p[g];
-                    h = alive ? h2 : h;
-                    alive = alive && (st[g].theta == -INFINITY || h2 >= st[g].theta);
+                    for (int g = 0; g < G; ++g) {
+                        if (t + g >= t_end) break;
+                        int cnt = __popcll(__ballot(alive));
+                        if (cnt && lane == 0) atomicAdd(&hist[t + g], (uint32_t)cnt);
+                        float h2 = h + p[g];
+                        h = alive ? h2 : h;
+                        alive = alive && (st[g].theta == -INFINITY || h2 >= st[g].theta);
+                    }
+                }
+                unsigned long long mask = __ballot(alive);
+                int cnt = __popcll(mask);
+                if (cnt) {
+                    // in place: n_out + rank <= qb + lane, and this wave already holds chunk qb in registers
+                    if (alive) queue[n_out + lane_rank(mask)] = make_uint2((uint32_t)pos, __float_as_uint(h));
+                    n_out += cnt;
                 }
             }
-            unsigned long long mask = __ballot(alive);
-            int cnt = __popcll(mask);
-            if (cnt) {
-                // in place: n_out + rank <= qb + lane, and this wave already holds chunk qb in registers
-                if (alive) queue[n_out + lane_rank(mask)] = make_uint2((uint32_t)pos, __float_as_uint(h));
-                n_out += cnt;
-            }
+            n_q = n_out;
+            t_begin = t_end;
         }
-        n_q = n_out;
-        t_begin = t_end;
+    };
+
+    constexpr int S_MERGE = 16;
+    if (T > S_MERGE) {
+        run_segments(S_MERGE);
+        if (a.dbg & 8) return;
+        // ---- workgroup-wide re-pack at stage S_MERGE: by now a wave keeps only a few percent of
+        //      its windows (half-empty chunks in every wave); pooled, the tile's survivors fill
+        //      whole chunks of 64 for one or two waves and the others are done.
+        uint2 ent[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) ent[k] = (k * 64 + lane < n_q) ? queue[k * 64 + lane] : make_uint2(0u, 0u);
+        if (lane == 0) wcnt[wave] = (uint32_t)n_q;
+        __syncthreads();
+        uint32_t total = 0, before = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            uint32_t c = wcnt[w];
+            if (w < wave) before += c;
+            total += c;
+        }
+        const bool merge = total <= 64u * WAVES;                  // same decision in every wave
+        __syncthreads();                                          // everyone has read wcnt and its own entries
+        if (merge) {
+            uint2 *wgq = reinterpret_cast<uint2 *>(smem + (size_t)tile_floats * 4);
+#pragma unroll
+            for (int k = 0; k < RPW; ++k)
+                if (k * 64 + lane < n_q) wgq[before + k * 64 + lane] = ent[k];
+            __syncthreads();
+            queue = wgq + 64 * wave;
+            int left = (int)total - 64 * wave;
+            n_q = left < 0 ? 0 : (left > 64 ? 64 : left);
+        }
+        t_begin = S_MERGE;           // (a wave that ran dry earlier may have been handed windows)
     }
+    run_segments(T);
+    if (a.dbg & 16) return;
 
     // ---- stage-parallel tail: one window at a time, lane i evaluates stage rs+i
     for (int rs = t_begin; rs < T && n_q > 0; rs += 64) {
@@ -321,6 +376,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         n_q = n_out;
     }
 
+    if (a.dbg & 32) return;
     // ---- epilogue: the wave queues now hold the windows alive after stage T-1.  One atomic per
     //      workgroup reserves their slots in one of the sharded output buffers.
     if (lane == 0) wcnt[wave] = (uint32_t)n_q;
@@ -332,11 +388,10 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         for (int w = 0; w < WAVES; ++w) total += wcnt[w];
         wg_base = total ? atomicAdd(a.det_count + shard, total) : 0u;
     }
-    uint32_t *al = a.alive + ((int64_t)b * a.n_levels + tile_d.level) * a.T;
-    for (int t = tid; t < T; t += NT) {
-        uint32_t v = hist[t];
-        if (v) atomicAdd(al + t, v);
-    }
+    // per-stage alive counts of this tile: a private row, plain coalesced stores (atomics on the
+    // shared [level][stage] counters made every wave of every tile queue up behind each other)
+    uint32_t *th = a.tile_hist + ((int64_t)b * a.n_tiles + blockIdx.x) * a.T;
+    for (int t = tid; t < T; t += NT) th[t] = hist[t];
     __syncthreads();
     if (n_q > 0) {
         uint32_t o = wg_base;
@@ -354,6 +409,35 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
                 dst[o + i] = d;
             }
         }
+    }
+}
+
+// alive[b][level][t] = sum over the level's tiles of tile_hist[b][tile][t]; grid (n_levels, batch),
+// 1024 threads = 16 groups x 64 stages: group g sums tiles lo+g, lo+g+16, ... (independent loads,
+// several in flight), then the 16 partial sums meet in LDS.
+__global__ __launch_bounds__(1024) void alive_reduce_kernel(const uint32_t *tile_hist, const int32_t *tile_csr,
+                                                             int n_levels, int n_tiles, int T, uint32_t *alive) {
+    __shared__ uint32_t part[16][64];
+    const int level = blockIdx.x, b = blockIdx.y;
+    const int lo = tile_csr[level], hi = tile_csr[level + 1];
+    const int32_t *order = tile_csr + n_levels + 1;
+    const int x = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + x;
+        uint32_t acc = 0;
+        if (t < T) {
+#pragma unroll 4
+            for (int j = lo + g; j < hi; j += 16) acc += tile_hist[((int64_t)b * n_tiles + order[j]) * T + t];
+        }
+        part[g][x] = acc;
+        __syncthreads();
+        if (g == 0 && t < T) {
+            uint32_t s = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += part[k][x];
+            alive[((int64_t)b * n_levels + level) * T + t] = s;
+        }
+        __syncthreads();
     }
 }
 
@@ -390,13 +474,16 @@ __global__ void boxes_kernel(const WbDet *det, int64_t n_det, const float *inv_s
     scores[i] = d.score;
 }
 
-#define WB_CASC_CONFIGS(X) X(8, 4) X(4, 4) X(2, 4) X(1, 4) X(4, 8) X(2, 8) X(1, 8) X(2, 16) X(1, 16)
+#define WB_CASC_CONFIGS(X) X(8, 4) X(4, 4) X(2, 4) X(1, 4) X(8, 8) X(4, 8) X(2, 8) X(1, 8) X(2, 16) X(1, 16)
 
 template <int D>
 int launch_depth(hipStream_t st, dim3 grid, const CascArgs &a, int rpw, int waves, size_t lds) {
 #define WB_X(R, W)                                                                                          \
     if (rpw == R && waves == W) {                                                                           \
         hipLaunchKernelGGL((cascade_tile_kernel<D, R, W>), grid, dim3(W * 64), lds, st, a, a.stages);       \
+        if (a.T > 0)                                                                                        \
+            hipLaunchKernelGGL(alive_reduce_kernel, dim3(a.n_levels, grid.y), dim3(1024),                          \
+                               0, st, a.tile_hist, a.tile_csr, a.n_levels, a.n_tiles, a.T, a.alive);         \
         WB_HIP_CHECK(hipGetLastError());                                                                    \
         return WB_OK;                                                                                       \
     }
@@ -435,18 +522,18 @@ int wb_cascade_prepare(int depth, int rpw, int waves) {
 }
 
 extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const float *chn, int64_t chn_stride,
-                                 int layout, int batch, const WbLevel *levels, int n_levels,
-                                 const WbTile *tiles, int n_tiles, WbDet *det, uint32_t *det_count,
-                                 uint32_t shard_capacity, uint32_t *alive) {
-    WB_REQUIRE(model && chn && levels && tiles && det_count && alive, "wb_cascade_launch: null pointer");
+                                 int batch, const WbLevel *levels, int n_levels,
+                                 const WbTile *tiles, const int32_t *tile_csr, int n_tiles, WbDet *det,
+                                 uint32_t *det_count, uint32_t shard_capacity, uint32_t *tile_hist,
+                                 uint32_t *alive) {
+    WB_REQUIRE(model && chn && levels && tiles && tile_csr && det_count && alive, "wb_cascade_launch: null pointer");
+    WB_REQUIRE(tile_hist || model->n_stages == 0, "wb_cascade_launch: tile_hist scratch is null");
     WB_REQUIRE(det || shard_capacity == 0, "wb_cascade_launch: det is null but capacity > 0");
     WB_REQUIRE(batch >= 1 && batch <= 65535, "wb_cascade_launch: batch %d out of range", batch);
     WB_REQUIRE(n_levels >= 1 && n_tiles >= 1, "wb_cascade_launch: empty launch");
-    WB_REQUIRE(layout == WB_LAYOUT_PLANAR || layout == WB_LAYOUT_HWC, "wb_cascade_launch: bad layout %d", layout);
     CascArgs a;
     a.chn = chn;
     a.chn_stride = chn_stride;
-    a.layout = layout;
     a.levels = levels;
     a.tiles = tiles;
     a.n_levels = n_levels;
@@ -461,6 +548,11 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const float
     a.det_count = det_count;
     a.det_cap = shard_capacity;
     a.alive = alive;
+    a.tile_hist = tile_hist;
+    a.tile_csr = tile_csr;
+    a.n_tiles = n_tiles;
+    static const int dbg = getenv("WB_CASC_DBG") ? atoi(getenv("WB_CASC_DBG")) : 0;
+    a.dbg = dbg;
     dim3 grid((unsigned)n_tiles, (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;
     switch (model->depth) {
@@ -499,3 +591,4 @@ extern "C" int wb_boxes_launch(void *stream, const WbDet *det, int64_t n_det, co
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;
 }
+

@@ -26,7 +26,6 @@ struct ChanArgs {
     const WbTile *tiles;
     const uint32_t *minmax;
     int n_oct;
-    int layout;
     float *chn;
     int64_t chn_stride;
     double cs[4], sn[4];
@@ -165,14 +164,12 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
 #pragma unroll
             for (int k = 0; k < U; ++k) {
                 int p = p0 + k * 256;
-                v[k] = T(0);
-                if (p < RH * RW) {
-                    int r = p / RW, q = p - r * RW;
-                    int y = ry0 + r, x = rx0 + q;
-                    y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
-                    x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
-                    v[k] = src[(int64_t)y * L.src_w + x];
-                }
+                p = p < RH * RW ? p : RH * RW - 1;           // clamped, unconditional load
+                int r = p / RW, q = p - r * RW;
+                int y = ry0 + r, x = rx0 + q;
+                y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
+                x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
+                v[k] = src[(int64_t)y * L.src_w + x];
             }
 #pragma unroll
             for (int k = 0; k < U; ++k)
@@ -287,7 +284,6 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
     constexpr int RPT = TU * TV / 256;
     static_assert(TU * TV % 256 == 0 && 256 % TV == 0, "tile must split into whole thread strips");
     float *out = a.chn + (int64_t)b * a.chn_stride + L.chn_off;
-    const int64_t plane = (int64_t)L.u * L.vp;
     const int j = tid % TV, i0 = (tid / TV) * RPT;
     const int sv = v0 + j;
     float o[RPT][4];
@@ -318,16 +314,9 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
         const int su = u0 + i0 + y;
         if (su >= L.u || sv >= L.v) continue;
         if (SMOOTH && (su == 0 || sv == 0 || su == L.u - 1 || sv == L.v - 1)) o[y][0] = o[y][1] = o[y][2] = o[y][3] = 0.0f;
-        if (a.layout == WB_LAYOUT_HWC) {
-            float4 *dst = reinterpret_cast<float4 *>(out + ((int64_t)su * L.v + sv) * 4);
-            *dst = make_float4(o[y][0], o[y][1], o[y][2], o[y][3]);
-        } else {
-            float *dst = out + (int64_t)su * L.vp + sv;
-            dst[0] = o[y][0];
-            dst[plane] = o[y][1];
-            dst[2 * plane] = o[y][2];
-            dst[3 * plane] = o[y][3];
-        }
+        // one float4 per pixel ([u][v][4]): 64 lanes store 1 KiB contiguous
+        float4 *dst = reinterpret_cast<float4 *>(out + ((int64_t)su * L.v + sv) * 4);
+        *dst = make_float4(o[y][0], o[y][1], o[y][2], o[y][3]);
     }
 }
 
@@ -406,12 +395,11 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
                                   int64_t oct_stride, int dtype, int batch, const WbLevel *levels,
                                   int n_levels, const WbTile *tiles, int n_tiles, const uint32_t *minmax,
                                   int n_oct, int shrink, int smooth, const double *cs_sn, float *chn,
-                                  int64_t chn_stride, int layout) {
+                                  int64_t chn_stride) {
     WB_REQUIRE(img && levels && tiles && minmax && cs_sn && chn, "wb_channels_launch: null pointer");
     WB_REQUIRE(batch >= 1 && n_levels >= 1 && n_tiles >= 1, "wb_channels_launch: empty launch");
     WB_REQUIRE(batch <= 65535, "wb_channels_launch: batch %d exceeds grid.y limit", batch);
     WB_REQUIRE(smooth == 0 || smooth == 1, "wb_channels_launch: smooth must be 0 or 1");
-    WB_REQUIRE(layout == WB_LAYOUT_PLANAR || layout == WB_LAYOUT_HWC, "wb_channels_launch: bad layout %d", layout);
     WB_REQUIRE(n_oct >= 1 && n_oct <= WB_MAX_OCTAVES, "wb_channels_launch: n_oct out of range");
     ChanArgs a;
     a.img = img;
@@ -422,7 +410,6 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
     a.tiles = tiles;
     a.minmax = minmax;
     a.n_oct = n_oct;
-    a.layout = layout;
     a.chn = chn;
     a.chn_stride = chn_stride;
     set_constants(a, cs_sn);

@@ -64,7 +64,7 @@ struct WbModel {
     int waves;        // wavefronts per workgroup
     int tile_rows;    // = rpw * waves
     int lds_rows;     // tile_rows + m - 1
-    int lds_pitch;    // (WB_CASC_TC + n - 1) rounded up to 4 floats
+    int lds_pitch;    // WB_CASC_TC + n - 1 pixels + 1 pad column
     int lds_bytes;
     int stage_dwords;
     int32_t *stages_dev;        // (n_stages + G) stage records with LDS float offsets

@@ -135,8 +135,7 @@ def sort_records(d):
 
 
 class PyramidEngine:
-    def __init__(self, H, W, dtype, shrink, n_per_oct, smooth, batch=1, layout=nat.WB_LAYOUT_PLANAR,
-                 exact_single=False, det_capacity=1 << 16):
+    def __init__(self, H, W, dtype, shrink, n_per_oct, smooth, batch=1, exact_single=False, det_capacity=1 << 16):
         import torch
         self.lib = nat.load()
         self.dev = nat.require_gpu()
@@ -144,7 +143,6 @@ class PyramidEngine:
         self.tdtype = _torch_dtype(dtype)
         self.wb_dtype = nat.WB_DTYPE_U8 if self.dtype == np.uint8 else nat.WB_DTYPE_F32
         self.batch = int(batch)
-        self.layout = layout
         self.plan = PyramidPlan(H, W, shrink, n_per_oct, smooth, exact_single=exact_single)
         self.exact_single = exact_single
         p = self.plan
@@ -152,14 +150,13 @@ class PyramidEngine:
         self.img = torch.empty((self.batch, p.H, p.W), dtype=self.tdtype, device=dev)
         self.oct = torch.empty((self.batch, p.oct_total), dtype=self.tdtype, device=dev)
         self.minmax = torch.zeros((self.batch, max(p.n_oct, 1), 2), dtype=torch.int32, device=dev)
-        table, total = p.level_table(layout)
+        table, total = p.level_table()
         self.chn_stride = int(total)
         self.level_np = table
         self.levels = torch.from_numpy(table.view(np.uint8).copy()).to(dev) if p.n_levels else None
         tiles = p.chan_tiles()
         self.n_chan_tiles = int(tiles.size)
         self.chan_tiles = torch.from_numpy(tiles.view(np.uint8).copy()).to(dev) if tiles.size else None
-        # zero-filled once: planar row padding [v, vp) is never written and must stay finite
         self.chn = torch.zeros((self.batch, self.chn_stride), dtype=torch.float32, device=dev)
         self.cs_sn = orientation_constants()
         self._oct_off = (C.c_int64 * max(p.n_oct, 1))(*[int(x) for x in p.oct_off[:max(p.n_oct, 1)]])
@@ -219,7 +216,7 @@ class PyramidEngine:
                                               p.n_levels, nat.ptr(self.chan_tiles), self.n_chan_tiles,
                                               nat.ptr(self.minmax), max(p.n_oct, 1), p.shrink, p.smooth,
                                               self.cs_sn.ctypes.data_as(C.POINTER(C.c_double)), nat.ptr(self.chn),
-                                              self.chn_stride, self.layout), "wb_channels_launch")
+                                              self.chn_stride), "wb_channels_launch")
 
     def run_channels(self):
         self.launch_octaves()
@@ -231,11 +228,14 @@ class PyramidEngine:
         stt = self._casc.get(key)
         if stt is None:
             tiles = self.plan.casc_tiles(dm.m, dm.n, dm.tile_rows, dm.tile_cols)
+            csr = self.plan.tile_csr(tiles, max(self.plan.n_levels, 1))
+            T1 = max(dm.n_stages, 1)
             stt = dict(
                 dm=dm, n_tiles=int(tiles.size),
                 tiles=torch.from_numpy(tiles.view(np.uint8).copy()).to(self.dev) if tiles.size else None,
-                alive=torch.zeros((self.batch, max(self.plan.n_levels, 1), max(dm.n_stages, 1)),
-                                  dtype=torch.int32, device=self.dev))
+                csr=torch.from_numpy(csr).to(self.dev),
+                tile_hist=torch.empty((self.batch, max(int(tiles.size), 1), T1), dtype=torch.int32, device=self.dev),
+                alive=torch.zeros((self.batch, max(self.plan.n_levels, 1), T1), dtype=torch.int32, device=self.dev))
             self._casc = {key: stt}          # one cascade resident per engine
         return stt
 
@@ -244,9 +244,10 @@ class PyramidEngine:
         if stt["n_tiles"] == 0:
             return stt
         nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.chn), self.chn_stride,
-                                             self.layout, self.batch, nat.ptr(self.levels), self.plan.n_levels,
-                                             nat.ptr(stt["tiles"]), stt["n_tiles"], nat.ptr(self.detb.recs),
-                                             nat.ptr(self.detb.counts), self.detb.cap, nat.ptr(stt["alive"])),
+                                             self.batch, nat.ptr(self.levels), self.plan.n_levels,
+                                             nat.ptr(stt["tiles"]), nat.ptr(stt["csr"]), stt["n_tiles"],
+                                             nat.ptr(self.detb.recs), nat.ptr(self.detb.counts), self.detb.cap,
+                                             nat.ptr(stt["tile_hist"]), nat.ptr(stt["alive"])),
                   "wb_cascade_launch")
         return stt
 
@@ -254,7 +255,8 @@ class PyramidEngine:
         """Zero the counters and scan every level of every image with cascade `dm`."""
         stt = self._casc_state(dm)
         self.detb.zero()
-        stt["alive"].zero_()
+        if stt["n_tiles"] == 0:
+            stt["alive"].zero_()
         return self.launch_cascade(dm)
 
     def run(self, dm):
@@ -310,11 +312,8 @@ class PyramidEngine:
         """Channels of level l of image b as a fresh HWC float32 ndarray [u,v,4]."""
         lv = self.plan.levels[l]
         off = int(self.level_np[l]["chn_off"])
-        u, v, vp = lv["u"], lv["v"], lv["vp"]
-        if self.layout == nat.WB_LAYOUT_HWC:
-            return self.chn[b, off:off + u * v * N_CHANNELS].reshape(u, v, N_CHANNELS).cpu().numpy()
-        t = self.chn[b, off:off + N_CHANNELS * u * vp].reshape(N_CHANNELS, u, vp)[:, :, :v]
-        return t.permute(1, 2, 0).contiguous().cpu().numpy()
+        u, v = lv["u"], lv["v"]
+        return self.chn[b, off:off + u * v * N_CHANNELS].reshape(u, v, N_CHANNELS).cpu().numpy()
 
 
 def nat_f32_key(f):
@@ -325,15 +324,15 @@ def nat_f32_key(f):
 _ENGINES = {}
 
 
-def get_engine(H, W, dtype, shrink, n_per_oct, smooth, batch=1, layout=nat.WB_LAYOUT_PLANAR, exact_single=False):
+def get_engine(H, W, dtype, shrink, n_per_oct, smooth, batch=1, exact_single=False):
     """Small cache of engines keyed by configuration (buffers are reused across calls)."""
     import torch
-    key = (int(H), int(W), np.dtype(dtype).str, int(shrink), int(n_per_oct), int(smooth), int(batch), int(layout),
+    key = (int(H), int(W), np.dtype(dtype).str, int(shrink), int(n_per_oct), int(smooth), int(batch),
            bool(exact_single), torch.cuda.current_device() if torch.cuda.is_available() else -1)
     e = _ENGINES.get(key)
     if e is None:
         if len(_ENGINES) >= 4:
             _ENGINES.pop(next(iter(_ENGINES)))
-        e = PyramidEngine(H, W, dtype, shrink, n_per_oct, smooth, batch, layout, exact_single)
+        e = PyramidEngine(H, W, dtype, shrink, n_per_oct, smooth, batch, exact_single)
         _ENGINES[key] = e
     return e

@@ -140,7 +140,7 @@ class Model:
         assert Cc == 4, f"Invalid number of channels. Expected {Cc} given 4."
         H, W = image.shape
         dm = self.device_cascade()
-        eng = _engine.get_engine(H, W, image.dtype, shrink, n_per_oct, smooth, 1, nat.WB_LAYOUT_PLANAR)
+        eng = _engine.get_engine(H, W, image.dtype, shrink, n_per_oct, smooth, 1)
         T = len(self)
         if eng.plan.n_levels == 0:
             return dict(boxes=np.empty((0, 4), "f"), scores=np.empty(0, "f"), level=np.empty(0, np.int32),
@@ -247,21 +247,23 @@ class _SingleLevel:
     def scan(self, dm):
         import torch
         from .plan import PyramidPlan
-        key = (dm.m, dm.n, dm.tile_rows, dm.tile_cols)
+        key = (dm.m, dm.n, dm.tile_rows, dm.tile_cols, dm.n_stages)
+        T = dm.n_stages
         if key not in self._tiles:
             tl = PyramidPlan._tiles([(max(self.u - dm.m, 0), max(self.v - dm.n, 0))], dm.tile_rows, dm.tile_cols)
-            self._tiles = {key: (int(tl.size), torch.from_numpy(tl.view(np.uint8).copy()).to(self.dev) if tl.size else None)}
-        n_tiles, tiles = self._tiles[key]
-        T = dm.n_stages
+            csr = PyramidPlan.tile_csr(tl, 1)
+            self._tiles = {key: (int(tl.size), torch.from_numpy(tl.view(np.uint8).copy()).to(self.dev) if tl.size else None,
+                                 torch.from_numpy(csr).to(self.dev),
+                                 torch.empty((max(int(tl.size), 1), max(T, 1)), dtype=torch.int32, device=self.dev))}
+        n_tiles, tiles, csr, tile_hist = self._tiles[key]
         alive = torch.zeros((1, 1, max(T, 1)), dtype=torch.int32, device=self.dev)
         while True:
             self.detb.zero()
-            alive.zero_()
             if n_tiles:
-                nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.X), 0, nat.WB_LAYOUT_HWC,
-                                                     1, nat.ptr(self.levels), 1, nat.ptr(tiles), n_tiles,
+                nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.X), 0,
+                                                     1, nat.ptr(self.levels), 1, nat.ptr(tiles), nat.ptr(csr), n_tiles,
                                                      nat.ptr(self.detb.recs), nat.ptr(self.detb.counts), self.detb.cap,
-                                                     nat.ptr(alive)), "wb_cascade_launch")
+                                                     nat.ptr(tile_hist), nat.ptr(alive)), "wb_cascade_launch")
             need = self.detb.max_count()
             if need <= self.detb.cap:
                 break

@@ -6,15 +6,15 @@ Everything in this module is NumPy/pure Python and runs without a GPU.
 
 HBM layout per image (one contiguous buffer each, images of a batch at a fixed stride):
   octaves   : octave k>=1 at element offset oct_off[k] (octave 0 is the image itself)
-  channels  : level l at float offset chn_off[l];  planar [4][u][vp] (vp = v rounded up to 4
-              floats so that every row start is 16-byte aligned for the cascade's float4
-              tile loads) or HWC [u][v][4] (what channel_pyramid hands to callers)
+  channels  : level l at float offset chn_off[l], [u][v][4]: one aligned float4 per pixel -- the
+              layout channel_pyramid hands to callers, 16-byte stores for the channel kernel and
+              one contiguous run per tile row for the cascade
 """
 import math
 
 import numpy as np
 
-from ._native import LEVEL_DTYPE, TILE_DTYPE, WB_LAYOUT_HWC, WB_LAYOUT_PLANAR
+from ._native import LEVEL_DTYPE, TILE_DTYPE
 
 N_CHANNELS = 4          # grad_hist with n_bins=4 (reference channels.py:40)
 CHAN_TILES = {1: (16, 64), 2: (16, 64), 4: (8, 32)}   # must match wb_channels_tile()
@@ -71,30 +71,27 @@ class PyramidPlan:
                     levels.append(dict(oct=o, h=h, w=w, nh=nh, nw=nw, scale=real_scale / shrink))
         for lv in levels:
             lv["u"], lv["v"] = lv["nh"] // shrink, lv["nw"] // shrink
-            lv["vp"] = (lv["v"] + 3) // 4 * 4
+            lv["vp"] = lv["v"]
             if lv["u"] >= 65536 or lv["v"] >= 65536:
                 raise ValueError("channel image larger than 65535 pixels per side")
         self.levels = levels
         self.n_levels = len(levels)
         self.scales = [lv["scale"] for lv in levels]
 
-        self._tables = {}
+        self._table = None
         self._chan_tiles = None
 
     # ------------------------------------------------------------------ layout
-    def chn_offsets(self, layout):
+    def chn_offsets(self):
         offs, acc = [], 0
         for lv in self.levels:
             offs.append(acc)
-            if layout == WB_LAYOUT_PLANAR:
-                acc += N_CHANNELS * lv["u"] * lv["vp"]
-            else:
-                acc += N_CHANNELS * lv["u"] * lv["v"]
+            acc += N_CHANNELS * lv["u"] * lv["v"]
         return offs, max(acc, 4)
 
-    def level_table(self, layout):
-        if layout not in self._tables:
-            offs, total = self.chn_offsets(layout)
+    def level_table(self):
+        if self._table is None:
+            offs, total = self.chn_offsets()
             t = np.zeros(self.n_levels, LEVEL_DTYPE)
             for i, lv in enumerate(self.levels):
                 t[i]["oct"] = lv["oct"]
@@ -106,8 +103,8 @@ class PyramidPlan:
                 # scipy zoom recomputes the step from the integer shapes in fp64
                 t[i]["sy"] = np.float64(lv["h"]) / np.float64(lv["nh"])
                 t[i]["sx"] = np.float64(lv["w"]) / np.float64(lv["nw"])
-            self._tables[layout] = (t, total)
-        return self._tables[layout]
+            self._table = (t, total)
+        return self._table
 
     # ------------------------------------------------------------------ tiles
     @staticmethod
@@ -126,6 +123,16 @@ class PyramidPlan:
             return np.zeros(0, TILE_DTYPE)
         nat = np.concatenate(parts)
         return nat[xcd_order(nat.size)]
+
+    @staticmethod
+    def tile_csr(tiles, n_levels):
+        """int32 [n_levels + 1 + n_tiles]: per level the range [start, end) into the trailing list
+        of (launch-order) tile indices belonging to it -- what the cascade's statistics reduction
+        walks (include/waldboost_hip.h: wb_cascade_launch)."""
+        order = np.argsort(tiles["level"], kind="stable").astype(np.int32)
+        counts = np.bincount(tiles["level"], minlength=n_levels)[:n_levels]
+        start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        return np.concatenate([start, order]).astype(np.int32)
 
     def chan_tiles(self):
         if self._chan_tiles is None:
