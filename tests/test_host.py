@@ -1,0 +1,214 @@
+"""CPU tests of the host logic: level plan, tile tables, wire format, Boxes, scalar handling,
+and that the C-ABI library loads and exports every symbol include/waldboost_hip.h declares
+(no compute calls: there is no GPU here)."""
+import os
+import re
+import zlib
+
+import numpy as np
+import pytest
+
+import waldboost_amd as wb
+from oracle import wb_oracle as orc
+from waldboost_amd import _native as nat
+from waldboost_amd.engine import theta_as_f32, orientation_constants, nat_f32_key
+from waldboost_amd.plan import PyramidPlan, xcd_order, octave_shapes
+from util import GOLDEN, golden_meta
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------ C ABI
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = nat.load()
+    header = open(os.path.join(ROOT, "include", "waldboost_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*(wb_\w+)\(", header, re.M))
+    assert declared == set(nat.SYMBOLS), (declared ^ set(nat.SYMBOLS))
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.wb_abi_version() == 1
+    assert lib.wb_last_error() is not None
+
+
+def test_abi_struct_sizes_match_header():
+    assert nat.LEVEL_DTYPE.itemsize == 64 and nat.TILE_DTYPE.itemsize == 8 and nat.DET_DTYPE.itemsize == 16
+    header = open(os.path.join(ROOT, "include", "waldboost_hip.h")).read()
+    assert int(re.search(r"#define WB_DET_SHARDS (\d+)", header).group(1)) == nat.WB_DET_SHARDS
+
+
+def test_channels_tile_query_and_argument_errors_without_gpu():
+    import ctypes as C
+    lib = nat.load()
+    tu, tv = C.c_int(), C.c_int()
+    assert lib.wb_channels_tile(2, C.byref(tu), C.byref(tv)) == 0 and (tu.value, tv.value) == (16, 64)
+    assert lib.wb_channels_tile(4, C.byref(tu), C.byref(tv)) == 0 and (tu.value, tv.value) == (8, 32)
+    assert lib.wb_channels_tile(3, C.byref(tu), C.byref(tv)) == nat.WB_ERR_UNSUPPORTED
+    assert b"shrink=3" in lib.wb_last_error()
+    # null pointers are rejected before any HIP call
+    assert lib.wb_octaves_launch(None, None, 0, 1, 16, 16, 256, None, 0, None, 1, None) == nat.WB_ERR_INVALID
+    with pytest.raises(ValueError):
+        nat.check(lib.wb_model_info(None, None), "wb_model_info")
+
+
+def test_compute_entry_points_fail_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(nat.NativeError):
+        wb.channels.grad_hist(np.zeros((16, 16), np.uint8))
+    M = wb.load(os.path.join(GOLDEN, "cfg1_d1_T32.pb"))
+    with pytest.raises(nat.NativeError):
+        M.detect(np.zeros((64, 64), np.uint8))
+
+
+# ------------------------------------------------------------------------------ plan
+@pytest.mark.parametrize("H,W,shrink,npo", [(480, 640, 2, 8), (1080, 1920, 2, 8), (2160, 3840, 4, 12), (97, 131, 1, 3), (7, 100, 2, 8)])
+def test_plan_matches_oracle_level_plan(H, W, shrink, npo):
+    p = PyramidPlan(H, W, shrink, npo)
+    ref = orc.level_plan(H, W, shrink, npo)
+    assert p.n_levels == len(ref) and p.octaves == orc.octave_shapes(H, W) == octave_shapes(H, W)
+    for lv, r in zip(p.levels, ref):
+        assert (lv["oct"], lv["nh"], lv["nw"], lv["scale"]) == (r["oct"], r["nh"], r["nw"], r["scale"])
+
+
+def test_plan_geometry_of_the_survey():
+    p = PyramidPlan(1080, 1920, 2, 8)
+    assert p.n_levels == 64 and p.n_loc(12, 12) == 3045278
+    ab = p.algorithmic_bytes(1)
+    assert ab["chn_write"] == 52029776 and abs(ab["total"] - 128.94e6) < 0.05e6
+    assert PyramidPlan(480, 640, 2, 8).n_loc(12, 12) == 407350
+    assert PyramidPlan(2160, 3840, 4, 12).n_loc(12, 12) == 4435665
+
+
+def test_tile_tables_cover_every_window_once_and_csr_groups_by_level():
+    p = PyramidPlan(300, 500, 2, 4)
+    tiles = p.casc_tiles(12, 12, 32, 64)
+    grid = p.window_grid(12, 12)
+    cover = [np.zeros((max(r, 1), max(c, 1)), np.int32) for r, c in grid]
+    for t in tiles:
+        r, c = grid[t["level"]]
+        cover[t["level"]][t["ty"] * 32:min(t["ty"] * 32 + 32, r), t["tx"] * 64:min(t["tx"] * 64 + 64, c)] += 1
+    for (r, c), cv in zip(grid, cover):
+        if r and c:
+            assert (cv[:r, :c] == 1).all()
+    csr = PyramidPlan.tile_csr(tiles, p.n_levels)
+    start, order = csr[:p.n_levels + 1], csr[p.n_levels + 1:]
+    assert sorted(order.tolist()) == list(range(tiles.size))
+    for l in range(p.n_levels):
+        assert (tiles["level"][order[start[l]:start[l + 1]]] == l).all()
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 63, 64, 1000, 1671])
+def test_xcd_order_is_a_permutation(n):
+    o = xcd_order(n)
+    assert sorted(o.tolist()) == list(range(n))
+    # workgroups b and b+8 (same XCD under round-robin dispatch) get neighbouring tiles
+    if n >= 16:
+        assert o[8] == o[0] + 1
+
+
+# ------------------------------------------------------------------------------ wire format
+def test_pb_roundtrip_is_byte_identical_to_the_reference_file(tmp_path):
+    src = os.path.join(GOLDEN, "mixed_d2_T24.pb")
+    M = wb.load(src)
+    out = tmp_path / "m.pb"
+    M.save(str(out))
+    assert out.read_bytes() == open(src, "rb").read()
+    meta = golden_meta()["pb_mixed"]
+    assert list(M.shape) == meta["shape"] and M.channel_opts["shrink"] == meta["shrink"]
+    assert M.channel_opts["n_per_oct"] == meta["n_per_oct"] and M.channel_opts["smooth"] == meta["smooth"]
+    assert wb.model.symbol_name(M.channel_opts["channels"]) == meta["func"] == "waldboost.channels.grad_hist"
+    th = [t if np.isfinite(t) else "-inf" for t in M.theta]
+    assert th == meta["theta"]
+    z = np.load(os.path.join(GOLDEN, "pb_mixed_fields.npz"))
+    for i, w in enumerate(M.classifier):
+        for k in ("feature", "threshold", "left", "right", "prediction"):
+            assert np.array_equal(getattr(w, k), z[f"t{i}_{k}"]), (i, k)
+        assert w.feature.dtype == np.uint8 and w.left.dtype == np.int8 and w.threshold.dtype == np.float32
+
+
+def test_pb_errors_and_allow_list(tmp_path):
+    bad = tmp_path / "bad.pb"
+    bad.write_bytes(b"not a model")
+    with pytest.raises(ValueError, match="Cannot read model"):
+        wb.load(str(bad))
+    # a model naming an unknown channel function is refused instead of eval()'d (reference model.py:27-29)
+    from waldboost_amd import model_pb2
+    p = model_pb2.Model()
+    p.shape.extend([12, 12, 4])
+    p.channel_opts.shrink, p.channel_opts.n_per_oct, p.channel_opts.smooth = 2, 8, 1
+    p.channel_opts.func = "os.system"
+    evil = tmp_path / "evil.pb"
+    evil.write_bytes(zlib.compress(p.SerializeToString(), 9))
+    with pytest.raises(ValueError, match="unknown channel function"):
+        wb.load(str(evil))
+
+
+def test_model_container_semantics():
+    M = wb.Model((12, 12, 4), dict(wb.default_channel_opts))
+    assert len(M) == 0 and not M and M.eval_cost == 0
+    t = wb.DTree([(1, 2, 3), None, None], [0.5, 0, 0], [1, -1, -1], [2, -1, -1], [0, -1, 1])
+    M.append(t, -0.25)
+    assert len(M) == 1 and bool(M) and M[0] == (t, -0.25) and list(M) == [(t, -0.25)]
+    assert t.feature.tolist() == [[1, 2, 3], [0, 0, 0], [0, 0, 0]] and t.node_idx.tolist() == [0] and t.depth() == 1
+    b = M.get_boxes(np.array([2, 3]), np.array([5, 7]), 0.25)
+    assert np.array_equal(b.get(), np.array([[20, 8, 68, 56], [28, 12, 76, 60]], np.float32))
+    assert len(M.get_boxes(np.array([]), np.array([]), 0.5)) == 0
+
+
+def test_boxes_container():
+    b = wb.Boxes(np.arange(8, dtype=np.float32).reshape(2, 4), scores=np.array([1.0, 2.0], np.float32))
+    assert len(b) == 2 and b.has_field("scores") and not b.has_field("label")
+    assert np.array_equal(b[1].get(), [[4, 5, 6, 7]]) and b[1].get_field("scores")[0] == 2.0
+    c = wb.concatenate([b, b.normalized(2.0)])
+    assert len(c) == 4 and np.array_equal(c.get()[2], [0, 2, 4, 6]) and c.get_field("scores").tolist() == [1, 2, 1, 2]
+    assert len(wb.concatenate([])) == 0
+    with pytest.raises(ValueError):
+        b.set_field("x", np.zeros(3))
+
+
+# ------------------------------------------------------------------------------ scalars / constants
+def test_theta_as_f32_follows_numpy2_promotion():
+    hs = np.array([0.1, np.nextafter(np.float32(0.1), np.float32(1)), np.nextafter(np.float32(0.1), np.float32(0))], np.float32)
+    for theta in (0.1, np.float64(0.1), np.float32(0.1), 1, np.int64(1), np.float64(1e300), float("-inf"), np.float64(-1e-50)):
+        with np.errstate(over="ignore"):
+            want = hs >= theta
+        got = hs >= theta_as_f32(theta)
+        assert np.array_equal(want, got), theta
+    assert np.isnan(theta_as_f32(float("nan")))
+
+
+def test_orientation_constants_are_the_reference_ones():
+    cs_sn = orientation_constants()
+    c, s = orc.orientation_table()
+    assert np.array_equal(cs_sn[:4], c) and np.array_equal(cs_sn[4:], s)
+    assert [float(x).hex() for x in cs_sn] == ['0x1.0000000000000p+0', '0x1.6a09e667f3bcdp-1', '0x1.1a62633145c07p-54',
+                                               '-0x1.6a09e667f3bccp-1', '0x0.0p+0', '0x1.6a09e667f3bccp-1',
+                                               '0x1.0000000000000p+0', '0x1.6a09e667f3bcdp-1']
+
+
+def test_f32_key_is_order_preserving():
+    v = np.array([-np.inf, -3.5, -0.0, 0.0, 1e-30, 2.0, np.inf], np.float32)
+    k = [int(nat_f32_key(x)) for x in v]
+    assert k == sorted(k) and len(set(k)) >= 6
+
+
+def test_uint8_projection_identity_holds_on_the_cpu_too():
+    """The claim behind csrc/wb_channels.hip:project_int, checked with NumPy over all gradient pairs."""
+    cs_sn = orientation_constants()
+    g = np.arange(-1020, 1021, dtype=np.float64)
+    GX, GY = np.meshgrid(g, g, indexing="ij")
+    chi = np.float32(cs_sn[5])
+    clo = np.float32(cs_sn[5] - np.float64(chi))
+    for k in range(4):
+        ref = np.abs((GX * cs_sn[k] - GY * cs_sn[4 + k]).astype(np.float32))
+        if k == 0:
+            fast = np.abs(GX).astype(np.float32)
+        elif k == 2:
+            fast = np.abs(GY).astype(np.float32)
+        else:
+            d = np.abs(GX - GY) if k == 1 else np.abs(GX + GY)
+            lo = (d.astype(np.float32) * clo).astype(np.float32)
+            fast = (d * np.float64(chi) + lo.astype(np.float64)).astype(np.float32)      # == fmaf(d, chi, d*clo)
+        slow = (GX != 0) & ((GY == 0) | (GX == GY) | (GX == -GY))
+        assert np.array_equal(fast[~slow].view(np.uint32), ref[~slow].view(np.uint32)), k
