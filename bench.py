@@ -144,6 +144,11 @@ def main():
             raise SystemExit("bench: GPU detections differ from the oracle -- refusing to time a wrong kernel")
         parity = {"image": "seed 0", "detections": int(ref["scores"].size), "eval_cost": ref["n_weak"] / ref["n_loc"], "bit_exact": True}
 
+    # every engine holds valid octaves / channels / detections before any partial loop is timed
+    for e in engines:
+        e.run(dm)
+    torch.cuda.synchronize()
+
     # ---- step functions
     if args.only == "all":
         if args.no_graph:
