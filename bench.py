@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="1080p images per step and GPU (configs[1] = 1, configs[2] = 64)")
     ap.add_argument("--pool", type=int, default=4, help="distinct resident image batches cycled through")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="HIP streams the steps are spread over (<= pool): consecutive steps work on different "
+                         "images, so their kernels may overlap on the GPU like frames of a video pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", type=int, default=0, help="diagnostic: keep only the first N stages of the cascade")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -170,21 +173,32 @@ def main():
         ev_done = [torch.cuda.Event() for _ in engines]      # step i's kernels finished
         ev_comm = [torch.cuda.Event() for _ in engines]      # step i's gather finished
 
+    n_streams = max(1, min(args.streams, P))
+    lanes = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream()]
+
     def run_steps(k0, k):
-        cur = torch.cuda.current_stream()
+        main = torch.cuda.current_stream()
+        for st in lanes:
+            if st is not main:
+                st.wait_stream(main)
         for i in range(k0, k0 + k):
-            j = i % P
-            if world > 1:
-                cur.wait_event(ev_comm[j])                   # buffer j free again
-            steps[j]()
-            if world > 1:
-                ev_done[j].record(cur)
-                with torch.cuda.stream(comm):
-                    comm.wait_event(ev_done[j])
-                    gath[j].gather(engines[j].detb)
-                    ev_comm[j].record(comm)
+            j = i % P                                        # engine j always runs on stream j % n_streams
+            st = lanes[j % n_streams]
+            with torch.cuda.stream(st):
+                if world > 1:
+                    st.wait_event(ev_comm[j])                # buffer j free again
+                steps[j]()
+                if world > 1:
+                    ev_done[j].record(st)
+                    with torch.cuda.stream(comm):
+                        comm.wait_event(ev_done[j])
+                        gath[j].gather(engines[j].detb)
+                        ev_comm[j].record(comm)
+        for st in lanes:
+            if st is not main:
+                main.wait_stream(st)
         if world > 1:
-            cur.wait_stream(comm)
+            main.wait_stream(comm)
 
     run_steps(0, args.warmup)
     torch.cuda.synchronize()
@@ -237,6 +251,7 @@ def main():
                                    f"window (12,12,4), 128-stage depth-2 cascade, {B} image(s)/step/GPU",
                        "batch_per_gpu": B, "levels": plan.n_levels, "windows_per_image": n_loc,
                        "launch": "eager" if args.no_graph else "hipGraph replay", "only": args.only,
+                       "streams": n_streams, "pool": P,
                        "collective": "all_gather of detection prefix per step (side stream)" if world > 1 else "none"},
             "mpixels_per_s": world * args.steps * B * H * W / dt / 1e6,
             "images_per_s": world * args.steps * B / dt,
