@@ -124,6 +124,8 @@ int wb_octaves_launch(void *stream, const void *img, int dtype, int batch, int H
 /* All levels of all images: bilinear resize (fp64) -> Sobel gradients -> 4 oriented
  * channels (fp64 projection) -> shrink -> 3x3 smooth, fused per tile.
  *   levels   dev  WbLevel[n_levels];  tiles dev WbTile[n_tiles] (tile = wb_channels_tile)
+ *   img/oct  as for wb_octaves_launch; both buffers must extend 16 bytes past their last element
+ *            (source rows are fetched with 4-byte-aligned dword loads)
  *   cs_sn    HOST double[8]: cos(theta_k), k=0..3 then sin(theta_k) (channels.py:43-46)
  *   chn      dev  float [u][v][4] per level, image b at chn + b*chn_stride, level l at
  *                 + levels[l].chn_off (16-byte aligned) */

@@ -30,6 +30,7 @@ struct ChanArgs {
     int64_t chn_stride;
     double cs[4], sn[4];
     float chi, clo;      // sin(pi/4) = chi + clo (two-float split) for the integer-gradient fast path
+    int dbg;             // diagnostics (WB_CHAN_DBG): 1 = stop after step 1, 2 = after step 2, 4 = skip the stores
 };
 
 struct Tap {          // one axis of the bilinear resample (scipy NI_ZoomShift, order 1)
@@ -57,8 +58,31 @@ __device__ inline Tap make_tap(int k, double step, int n_in) {
     return t;
 }
 
+// scipy's order-1 resample of one output pixel: fp64, taps and additions in NI_ZoomShift's order
+__device__ inline double resample_f64(double v00, double v01, double v10, double v11, const Tap &tr, const Tap &tc) {
+    double t = (v00 * tr.w0) * tc.w0;
+    t = t + (v01 * tr.w0) * tc.w1;
+    t = t + (v10 * tr.w1) * tc.w0;
+    t = t + (v11 * tr.w1) * tc.w1;
+    return t;
+}
+
 template <typename T> struct Src;
 template <> struct Src<uint8_t> {
+    static constexpr bool kFastResample = true;
+    // The uint8 result is floor(clip(t)), so only the integer part of t matters.  An fp32 estimate
+    // (4 bytes x weights rounded to fp32, fma chain) is within 1.1e-4 of the exact sum, and scipy's
+    // fp64 value within 1e-12: unless the estimate lies within EPS of an integer both have the same
+    // floor.  Lanes inside that band (flat 2x2 patches always are) redo the pixel in fp64.
+    static constexpr float kEps = 2.5e-4f;
+    static __device__ bool fast(float v00, float v01, float v10, float v11, float wr0, float wr1, float wc0, float wc1,
+                                float mn, float mx, float &out) {
+        float top = __builtin_fmaf(v01, wc1, v00 * wc0), bot = __builtin_fmaf(v11, wc1, v10 * wc0);
+        float t = __builtin_fmaf(bot, wr1, top * wr0);
+        float fl = floorf(t), fr = t - fl;
+        out = fminf(fmaxf(fl, mn), mx);
+        return !(fr < kEps || fr > 1.0f - kEps);
+    }
     static __device__ double lo(uint32_t k) { return (double)k; }
     // fp64 result is clipped in fp64, then cast to uint8 by truncation
     static __device__ float finish(double t, double mn, double mx) {
@@ -70,6 +94,8 @@ template <> struct Src<uint8_t> {
     static __device__ float dpass(float lo, float hi) { return lo - hi; }
 };
 template <> struct Src<float> {
+    static constexpr bool kFastResample = false;
+    static __device__ bool fast(float, float, float, float, float, float, float, float, float, float, float &) { return false; }
     static __device__ double lo(uint32_t k) { return (double)wb_key_f32(k); }
     // float32 images: zoom stores fp32, then np.clip in fp32
     static __device__ float finish(double t, double mn, double mx) {
@@ -137,10 +163,17 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
     constexpr int RH = S * SU + 2, RW = S * SV + 2;    // resized tile incl. Sobel halo
     constexpr int P = S + 2;                           // patch side per shrunk pixel
 
-    __shared__ Tap rowtab[RH];
-    __shared__ Tap coltab[RW];
+    // LDS: R (resized tile) | one region shared by the uint8 source patch (live in step 1 only)
+    // and the shrunk tile Sh (live from step 2 on)
+    // source patch capacity: no larger than Sh, so that R + region stay under 40 KiB (4 workgroups
+    // per CU); tiles of the most down-scaled levels of an octave that do not fit take the direct path
+    constexpr int PROWS = 2 * RH + 4, PPITCH = ((SU * SV * 16) / PROWS) & ~3;
+    constexpr int SH_BYTES = SU * SV * 16;
+    constexpr int PATCH_BYTES = sizeof(T) == 1 ? PROWS * PPITCH : 0;
+    constexpr int UNI_BYTES = SH_BYTES > PATCH_BYTES ? SH_BYTES : PATCH_BYTES;
     __shared__ float R[RH * RW];
-    __shared__ __attribute__((aligned(16))) F4 Sh[SU * SV];
+    __shared__ __attribute__((aligned(16))) unsigned char uni[UNI_BYTES];
+    F4 *Sh = reinterpret_cast<F4 *>(uni);
 
     const WbTile tile = a.tiles[blockIdx.x];
     const WbLevel L = a.levels[tile.level];
@@ -154,74 +187,174 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
     const double mn = Src<T>::lo(~mm[0]), mx = Src<T>::lo(mm[1]);   // mm[0] holds max(~key)
 
     const int ry0 = S * (u0 - HS) - 1, rx0 = S * (v0 - HS) - 1;
+    // ---- step 1: bilinear resample of the tile (+ Sobel halo) into R, cast back to the image dtype.
+    //      One tile row per wave at a time: the row's taps are wave-uniform (scalar registers,
+    //      scalar row base pointers), the column taps of a lane's NCS columns live in registers,
+    //      and the 4*NCS source loads of a row are issued before any arithmetic.  Coordinates are
+    //      clamped to the level = the 'reflect' halo of convolve1d for a 1-pixel border.
+    //      The RW % 64 right-most columns are done afterwards, one pixel per thread.
+    constexpr int NCS = RW / 64, MAINW = NCS * 64, LEFT = RW - MAINW;
+    const int lane = tid & 63, wave = tid >> 6;
     // Levels at their octave's own size (scale 1: every level i=0 with even dims) resample with
-    // weights (1, 0): t = v*1*1 + 0 + 0 + 0 = v exactly, so the tile is a plain copy.
+    // weights (1, 0): t = v*1*1 + 0 + 0 + 0 = v exactly -> plain copy.
     const bool ident = (L.src_h == L.nh) && (L.src_w == L.nw);
-    if (ident) {
-        constexpr int U = 4;
-        for (int p0 = tid; p0 < RH * RW; p0 += 256 * U) {
-            T v[U];
+    const float mnf = (float)mn, mxf = (float)mx;
+    // uint8 images: the tile's source patch (rows r_lo..r_hi, columns c_lo..c_hi of the octave) is
+    // first copied to LDS with coalesced dword loads; the 4 taps of every pixel are then LDS byte
+    // reads.  (Fetched straight from HBM they were 4 byte-gathers per pixel and the texture-address
+    // unit, not the ALUs, set the pace.)  Falls back to direct loads if the patch would not fit
+    // (strongly down-scaled tiny levels) and for float32 images.
+    bool staged = false;
+    int r_lo = 0, c_lo = 0;
+    if constexpr (sizeof(T) == 1) {
+        int yf = ry0 < 0 ? 0 : (ry0 > L.nh - 1 ? L.nh - 1 : ry0);
+        int yl = ry0 + RH - 1; yl = yl < 0 ? 0 : (yl > L.nh - 1 ? L.nh - 1 : yl);
+        int xf = rx0 < 0 ? 0 : (rx0 > L.nw - 1 ? L.nw - 1 : rx0);
+        int xl = rx0 + RW - 1; xl = xl < 0 ? 0 : (xl > L.nw - 1 ? L.nw - 1 : xl);
+        const Tap t_yf = make_tap(yf, L.sy, L.src_h), t_yl = make_tap(yl, L.sy, L.src_h);
+        const Tap t_xf = make_tap(xf, L.sx, L.src_w), t_xl = make_tap(xl, L.sx, L.src_w);
+        r_lo = t_yf.i0 < t_yf.i1 ? t_yf.i0 : t_yf.i1;
+        c_lo = t_xf.i0 < t_xf.i1 ? t_xf.i0 : t_xf.i1;
+        const int r_hi = t_yl.i0 > t_yl.i1 ? t_yl.i0 : t_yl.i1;
+        const int c_hi = t_xl.i0 > t_xl.i1 ? t_xl.i0 : t_xl.i1;
+        const int nrow = r_hi - r_lo + 1, nbyte = c_hi - c_lo + 1;
+        staged = !ident && nrow <= PROWS && nbyte + 8 <= PPITCH;
+        if (staged) {
+            constexpr int DWP = PPITCH / 4;                       // dwords per patch row
+            const int ndw = (nbyte + 3 + 3) / 4;                  // worst case alignment slack on both ends
+            const uint32_t m_ndw = 0xFFFFFFFFu / (uint32_t)ndw + 1u;
+            const int total = nrow * ndw;
+            uint32_t *pw = reinterpret_cast<uint32_t *>(uni);
+            constexpr int U = 8;
+            for (int e0 = tid; e0 < total; e0 += 256 * U) {
+                uint32_t v[U];
+                int dst[U];
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                int p = p0 + k * 256;
-                p = p < RH * RW ? p : RH * RW - 1;           // clamped, unconditional load
-                int r = p / RW, q = p - r * RW;
-                int y = ry0 + r, x = rx0 + q;
-                y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
-                x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
-                v[k] = src[(int64_t)y * L.src_w + x];
+                for (int k = 0; k < U; ++k) {
+                    uint32_t e = (uint32_t)(e0 + k * 256);
+                    e = e < (uint32_t)total ? e : (uint32_t)total - 1u;
+                    uint32_t row = __umulhi(e, m_ndw), dw = e - row * (uint32_t)ndw;
+                    // the row's first needed byte, aligned down to 4 (the buffers carry 16 spare bytes)
+                    uintptr_t addr = reinterpret_cast<uintptr_t>(src + (int64_t)(r_lo + (int)row) * L.src_w + c_lo) & ~(uintptr_t)3;
+                    v[k] = reinterpret_cast<const uint32_t *>(addr)[dw];
+                    dst[k] = (int)row * DWP + (int)dw;
+                }
+#pragma unroll
+                for (int k = 0; k < U; ++k) pw[dst[k]] = v[k];           // duplicates rewrite the same value
             }
-#pragma unroll
-            for (int k = 0; k < U; ++k)
-                if (p0 + k * 256 < RH * RW) R[p0 + k * 256] = (float)v[k];
+            __syncthreads();
         }
-    } else {
-        // ---- step 0: per-row / per-column resampling taps (coordinates clamped = 'reflect'
-        //      halo of convolve1d for a 1-pixel border)
-        for (int k = tid; k < RH + RW; k += 256) {
-            if (k < RH) {
+    }
+    if (staged) {
+        if constexpr (sizeof(T) == 1) {
+            const unsigned char *patch = uni;
+            int ci0[NCS], ci1[NCS];
+            float wc0f[NCS], wc1f[NCS];
+            Tap tc[NCS];
+#pragma unroll
+            for (int c = 0; c < NCS; ++c) {
+                int x = rx0 + lane + 64 * c;
+                x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
+                tc[c] = make_tap(x, L.sx, L.src_w);
+                ci0[c] = tc[c].i0 - c_lo;
+                ci1[c] = tc[c].i1 - c_lo;
+                wc0f[c] = (float)tc[c].w0;
+                wc1f[c] = (float)tc[c].w1;
+            }
+            const uintptr_t base = reinterpret_cast<uintptr_t>(src);
+            for (int k = wave; k < RH; k += 4) {
                 int y = ry0 + k;
                 y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
-                rowtab[k] = make_tap(y, L.sy, L.src_h);
-            } else {
-                int x = rx0 + (k - RH);
-                x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
-                coltab[k - RH] = make_tap(x, L.sx, L.src_w);
+                const Tap tr = make_tap(__builtin_amdgcn_readfirstlane(y), L.sy, L.src_h);
+                const int i0 = __builtin_amdgcn_readfirstlane(tr.i0), i1 = __builtin_amdgcn_readfirstlane(tr.i1);
+                // byte offset of column c_lo inside the row's LDS image = its misalignment in memory
+                const int o0 = (i0 - r_lo) * PPITCH + (int)((base + (uintptr_t)((int64_t)i0 * L.src_w + c_lo)) & 3);
+                const int o1 = (i1 - r_lo) * PPITCH + (int)((base + (uintptr_t)((int64_t)i1 * L.src_w + c_lo)) & 3);
+                const float wr0 = (float)tr.w0, wr1 = (float)tr.w1;
+#pragma unroll
+                for (int c = 0; c < NCS; ++c) {
+                    const unsigned char a00 = patch[o0 + ci0[c]], a01 = patch[o0 + ci1[c]];
+                    const unsigned char a10 = patch[o1 + ci0[c]], a11 = patch[o1 + ci1[c]];
+                    float out;
+                    if (!Src<T>::fast((float)a00, (float)a01, (float)a10, (float)a11, wr0, wr1, wc0f[c], wc1f[c], mnf, mxf, out))
+                        out = Src<T>::finish(resample_f64((double)a00, (double)a01, (double)a10, (double)a11, tr, tc[c]), mn, mx);
+                    R[k * RW + lane + 64 * c] = out;
+                }
             }
         }
-        __syncthreads();
-
-        // ---- step 1: bilinear resample into R (fp64, scipy tap order), cast back to the image
-        //      dtype.  U pixels per pass: their 4*U source loads are issued before any arithmetic.
-        constexpr int U = 4;
-        for (int p0 = tid; p0 < RH * RW; p0 += 256 * U) {
-            T v00[U], v01[U], v10[U], v11[U];
-            double wr0[U], wr1[U], wc0[U], wc1[U];
+    } else
+    {
+        Tap tc[NCS];
+        float wc0f[NCS], wc1f[NCS];
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                int p = p0 + k * 256;
-                p = p < RH * RW ? p : RH * RW - 1;
-                int r = p / RW, q = p - r * RW;
-                Tap tr = rowtab[r], tc = coltab[q];
-                const T *r0 = src + (int64_t)tr.i0 * L.src_w;
-                const T *r1 = src + (int64_t)tr.i1 * L.src_w;
-                v00[k] = r0[tc.i0];
-                v01[k] = r0[tc.i1];
-                v10[k] = r1[tc.i0];
-                v11[k] = r1[tc.i1];
-                wr0[k] = tr.w0; wr1[k] = tr.w1; wc0[k] = tc.w0; wc1[k] = tc.w1;
+        for (int c = 0; c < NCS; ++c) {
+            int x = rx0 + lane + 64 * c;
+            x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
+            tc[c] = make_tap(x, L.sx, L.src_w);
+            wc0f[c] = (float)tc[c].w0;
+            wc1f[c] = (float)tc[c].w1;
+        }
+        // RB rows per pass: all their source loads are in flight before the first one is used
+        // (one row at a time, the loop was a chain of RH/4 memory latencies per wave)
+        constexpr int RB = 5;
+        for (int k0 = wave; k0 < RH; k0 += 4 * RB) {
+            Tap tr[RB];
+            T v00[RB][NCS], v01[RB][NCS], v10[RB][NCS], v11[RB][NCS];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                int k = k0 + 4 * rb;
+                k = k < RH ? k : RH - 1;                                  // clamped, unconditional loads
+                int y = ry0 + k;
+                y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
+                tr[rb] = make_tap(__builtin_amdgcn_readfirstlane(y), L.sy, L.src_h);
+                const T *r0 = src + (int64_t)__builtin_amdgcn_readfirstlane(tr[rb].i0) * L.src_w;
+                const T *r1 = src + (int64_t)__builtin_amdgcn_readfirstlane(tr[rb].i1) * L.src_w;
+#pragma unroll
+                for (int c = 0; c < NCS; ++c) {
+                    v00[rb][c] = r0[tc[c].i0];
+                    v01[rb][c] = r0[tc[c].i1];
+                    v10[rb][c] = r1[tc[c].i0];
+                    v11[rb][c] = r1[tc[c].i1];
+                }
             }
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                double t = ((double)v00[k] * wr0[k]) * wc0[k];
-                t = t + ((double)v01[k] * wr0[k]) * wc1[k];
-                t = t + ((double)v10[k] * wr1[k]) * wc0[k];
-                t = t + ((double)v11[k] * wr1[k]) * wc1[k];
-                if (p0 + k * 256 < RH * RW) R[p0 + k * 256] = Src<T>::finish(t, mn, mx);
+            for (int rb = 0; rb < RB; ++rb) {
+                const int k = k0 + 4 * rb;
+#pragma unroll
+                for (int c = 0; c < NCS; ++c) {
+                    float out = 0.0f;
+                    if (ident) {
+                        out = (float)v00[rb][c];
+                    } else {
+                        bool ok = false;
+                        if constexpr (Src<T>::kFastResample)
+                            ok = Src<T>::fast((float)v00[rb][c], (float)v01[rb][c], (float)v10[rb][c], (float)v11[rb][c],
+                                              (float)tr[rb].w0, (float)tr[rb].w1, wc0f[c], wc1f[c], mnf, mxf, out);
+                        if (!ok)
+                            out = Src<T>::finish(resample_f64((double)v00[rb][c], (double)v01[rb][c], (double)v10[rb][c],
+                                                              (double)v11[rb][c], tr[rb], tc[c]), mn, mx);
+                    }
+                    if (k < RH) R[k * RW + lane + 64 * c] = out;
+                }
             }
         }
     }
+    if constexpr (LEFT > 0) {
+        for (int p = tid; p < RH * LEFT; p += 256) {
+            const int k = p / LEFT, q = MAINW + p - k * LEFT;
+            int y = ry0 + k, x = rx0 + q;
+            y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
+            x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
+            const Tap tr = make_tap(y, L.sy, L.src_h), tc = make_tap(x, L.sx, L.src_w);
+            const T *r0 = src + (int64_t)tr.i0 * L.src_w;
+            const T *r1 = src + (int64_t)tr.i1 * L.src_w;
+            const T a00 = r0[tc.i0], a01 = r0[tc.i1], a10 = r1[tc.i0], a11 = r1[tc.i1];
+            R[k * RW + q] = ident ? (float)a00
+                                  : Src<T>::finish(resample_f64((double)a00, (double)a01, (double)a10, (double)a11, tr, tc), mn, mx);
+        }
+    }
     __syncthreads();
+    if (a.dbg & 1) return;
 
     // ---- step 2: gradients -> 4 oriented channels -> shrink, one shrunk pixel per iteration
     for (int p = tid; p < SU * SV; p += 256) {
@@ -278,6 +411,7 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
     }
     __syncthreads();
 
+    if (a.dbg & 2) return;
     // ---- step 3: 3x3 binomial smooth (fp64 sum in source order, /16, one rounding), border = 0.
     //      Each thread owns RPT vertically adjacent outputs of one column, so every shrunk value
     //      it needs is read and widened to fp64 once for up to three output rows.
@@ -312,7 +446,7 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
 #pragma unroll
     for (int y = 0; y < RPT; ++y) {
         const int su = u0 + i0 + y;
-        if (su >= L.u || sv >= L.v) continue;
+        if (su >= L.u || sv >= L.v || (a.dbg & 4)) continue;
         if (SMOOTH && (su == 0 || sv == 0 || su == L.u - 1 || sv == L.v - 1)) o[y][0] = o[y][1] = o[y][2] = o[y][3] = 0.0f;
         // one float4 per pixel ([u][v][4]): 64 lanes store 1 KiB contiguous
         float4 *dst = reinterpret_cast<float4 *>(out + ((int64_t)su * L.v + sv) * 4);
@@ -413,6 +547,8 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
     a.chn = chn;
     a.chn_stride = chn_stride;
     set_constants(a, cs_sn);
+    static const int dbg = getenv("WB_CHAN_DBG") ? atoi(getenv("WB_CHAN_DBG")) : 0;
+    a.dbg = dbg;
     dim3 grid((unsigned)n_tiles, (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == WB_DTYPE_U8) {

@@ -147,8 +147,12 @@ class PyramidEngine:
         self.exact_single = exact_single
         p = self.plan
         dev = self.dev
-        self.img = torch.empty((self.batch, p.H, p.W), dtype=self.tdtype, device=dev)
-        self.oct = torch.empty((self.batch, p.oct_total), dtype=self.tdtype, device=dev)
+        # flat allocations with 16 spare elements: the channel kernel fetches source rows with
+        # 4-byte-aligned dword loads that may touch a few bytes past the last row
+        self._img_flat = torch.zeros(self.batch * p.H * p.W + 16, dtype=self.tdtype, device=dev)
+        self.img = self._img_flat[: self.batch * p.H * p.W].view(self.batch, p.H, p.W)
+        self._oct_flat = torch.zeros(self.batch * p.oct_total + 16, dtype=self.tdtype, device=dev)
+        self.oct = self._oct_flat[: self.batch * p.oct_total].view(self.batch, p.oct_total)
         self.minmax = torch.zeros((self.batch, max(p.n_oct, 1), 2), dtype=torch.int32, device=dev)
         table, total = p.level_table()
         self.chn_stride = int(total)
