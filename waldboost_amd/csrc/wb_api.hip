@@ -121,7 +121,9 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         M->waves = waves;
         M->tile_rows = rpw * waves;
         M->lds_rows = M->tile_rows + m - 1;
-        M->lds_bytes = C * M->lds_rows * M->lds_pitch * 4 + M->tile_rows * WB_CASC_TC * 8 + n_stages * 4;
+        M->lds_stages = (n_stages * WB_STAGE_DWORDS(D) * 4 <= 16 * 1024) ? n_stages : 0;
+        M->lds_bytes = ((C * M->lds_rows * M->lds_pitch * 4 + M->tile_rows * WB_CASC_TC * 8 + n_stages * 4 + 15) & ~15) +
+                       M->lds_stages * WB_STAGE_DWORDS(D) * 4;
         if (M->lds_bytes <= budget || rpw <= 1) break;
     }
     if (M->lds_bytes > 160 * 1024) {

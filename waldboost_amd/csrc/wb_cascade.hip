@@ -42,6 +42,7 @@ struct CascArgs {
     const int32_t *stages;      // stage records with LDS float offsets
     int T, m, n, C;
     int lds_rows, lds_pitch;
+    int lds_stages;             // stage records mirrored in LDS for the stage-parallel tail (0 = read them from HBM)
     WbDet *det;
     uint32_t *det_count;
     uint32_t det_cap;           // per shard
@@ -149,7 +150,10 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     const int nc = L.v - a.n > 0 ? L.v - a.n : 0;
     const int r0 = tile_d.ty * TR, c0 = tile_d.tx * WB_CASC_TC;
 
+    // LDS mirror of the stage table (when it is small enough): the tail reads one record per lane
+    int4 *stab = reinterpret_cast<int4 *>(smem + (((size_t)tile_floats * 4 + (size_t)TR * 64 * 8 + (size_t)T * 4 + 15) & ~(size_t)15));
     for (int t = tid; t < T; t += NT) hist[t] = 0;
+    for (int i = tid; i < a.lds_stages * (SD / 4); i += NT) stab[i] = reinterpret_cast<const int4 *>(stages)[i];
 
     // ---- stage the channel block into LDS (planar [C][rows][pitch])
     const float *chn = a.chn + (int64_t)b * a.chn_stride + L.chn_off;
@@ -347,7 +351,24 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         const int t = rs + lane;
         const int nvalid = T - rs < 64 ? T - rs : 64;
         Stage<D> st;                                             // this lane's own stage
-        st.load(stages + (size_t)(t < T ? t : T - 1) * SD);
+        {
+            const int tt = t < T ? t : T - 1;
+            int32_t rec[SD];
+            if (a.lds_stages) {
+#pragma unroll
+                for (int q = 0; q < SD / 4; ++q) {
+                    int4 v = stab[tt * (SD / 4) + q];
+                    rec[4 * q] = v.x; rec[4 * q + 1] = v.y; rec[4 * q + 2] = v.z; rec[4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < SD / 4; ++q) {
+                    int4 v = reinterpret_cast<const int4 *>(stages)[(size_t)tt * (SD / 4) + q];
+                    rec[4 * q] = v.x; rec[4 * q + 1] = v.y; rec[4 * q + 2] = v.z; rec[4 * q + 3] = v.w;
+                }
+            }
+            st.load(rec);
+        }
         int n_out = 0;
         for (int i = 0; i < n_q; ++i) {
             const uint2 e = queue[i];                            // same entry in every lane
@@ -357,11 +378,15 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
             // Replay in stage order: lane k accumulates p_0 .. p_k one after the other -- the same
             // additions in the same order as the reference's running `hs +=` -- so it ends up
             // with the score the rejection test of stage rs+k sees.
-            float hk = __uint_as_float(e.y);
+            // (ripple through the wave with DPP wave_shr:1 -- lane k takes lane k-1's running sum
+            // and adds its own p; after step k+1 lane k is final and later steps recompute the
+            // same value, so 64 steps settle every lane)
+            const float h_in = __uint_as_float(e.y);
+            float hk = h_in;
 #pragma unroll
             for (int j = 0; j < 64; ++j) {
-                float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), j));
-                if (lane >= j) hk = hk + pj;
+                int prev = __builtin_amdgcn_update_dpp(__float_as_int(h_in), __float_as_int(hk), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                hk = __int_as_float(prev) + p;
             }
             const bool rej = (lane < nvalid) && (st.theta != -INFINITY) && !(hk >= st.theta);
             const unsigned long long rmask = __ballot(rej);
@@ -544,6 +569,7 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const float
     a.C = model->C;
     a.lds_rows = model->lds_rows;
     a.lds_pitch = model->lds_pitch;
+    a.lds_stages = model->lds_stages;
     a.det = det;
     a.det_count = det_count;
     a.det_cap = shard_capacity;

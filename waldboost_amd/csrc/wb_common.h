@@ -66,6 +66,7 @@ struct WbModel {
     int lds_rows;     // tile_rows + m - 1
     int lds_pitch;    // WB_CASC_TC + n - 1 pixels + 1 pad column
     int lds_bytes;
+    int lds_stages;   // stage records mirrored in LDS (n_stages if the table is <= 16 KiB, else 0)
     int stage_dwords;
     int32_t *stages_dev;        // (n_stages + G) stage records with LDS float offsets
 };
