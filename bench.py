@@ -46,7 +46,7 @@ def _cpu_worker(seed):
     return res["n_loc"], time.perf_counter() - t0
 
 
-def cpu_baseline(images_per_core=1, max_cores=16):
+def cpu_baseline(images_per_core=6, max_cores=16):
     import multiprocessing as mp
     cores = max(1, min(max_cores, os.cpu_count() or 1))
     n = cores * images_per_core
@@ -230,11 +230,14 @@ def main():
         name = "channels_kernel" if kern["channels_ms"] >= kern["cascade_ms"] else "cascade_kernel"
         ms = kern["channels_ms"] if name == "channels_kernel" else kern["cascade_ms"]
         abytes = ab[name] * B
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (batch-1 launches only)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_pmc.json")
+        if os.path.exists(tpath) and B == 1:
             with open(tpath) as f:
-                traffic = json.load(f).get(f"{name}_b{B}")
+                tj = json.load(f)
+            key = "channels_kernel" if name == "channels_kernel" else "cascade_tile_kernel"
+            traffic = tj.get(key, {}).get("traffic_bytes_per_launch_b1")
         roof = {"bound": "hbm", "kernel": name, "achieved": abytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": ms}
