@@ -295,3 +295,29 @@ def test_uint8_fast_and_generic_projection_agree(monkeypatch):
     ref = [c for c, _ in orc.channel_pyramid(img, dict(o, channels=orc.grad_hist))]
     for a, b in zip(fast, ref):
         assert np.array_equal(bits(a), bits(b))
+
+
+def test_multi_model_detect_shares_one_pyramid():
+    """waldboost.detect (reference __init__.py:75-130): level-major, then model, then row-major."""
+    img = synth_image(300, 420, 77)
+    models = [random_model(500 + k, 20 + 5 * k, 2 if k else 1) for k in range(3)]
+    rs = [1.0, 2.5, 0.5]
+    out = wb.detect(img, *models, response_scale=rs)
+    refs = [oracle_detect(M, img) for M in models]
+    boxes, scores, labels = [], [], []
+    n_levels = refs[0]["alive"].shape[0]
+    for lv in range(n_levels):
+        for k, r in enumerate(refs):
+            sel = r["level"] == lv
+            if sel.any():
+                boxes.append(r["boxes"][sel])
+                scores.append(r["scores"][sel] * np.float32(rs[k]))
+                labels.append(np.full(int(sel.sum()), k, np.int64))
+    assert len(out) == sum(len(b) for b in boxes) > 0
+    assert np.array_equal(out.get(), np.concatenate(boxes))
+    assert np.array_equal(bits(out.get_field("scores")), bits(np.concatenate(scores)))
+    assert np.array_equal(out.get_field("label"), np.concatenate(labels))
+    for M, r in zip(models, refs):
+        assert M.n_loc == r["n_loc"] and M.n_weak == r["n_weak"]
+    with pytest.raises(ValueError):
+        wb.detect(img, *models, response_scale=[1.0])

@@ -22,7 +22,50 @@ def save_model(model, filename):
 
 save = save_model
 
+def detect(image, *models, channel_opts=None, response_scale=None):
+    """Detect objects with several models sharing one channel pyramid (reference
+    waldboost/__init__.py:75-130): returns Boxes with 'scores' (multiplied by response_scale[k]) and
+    'label' (index of the model that fired).  Order: pyramid level, then model, then row-major
+    window order -- as the reference's nested loops produce it.  The reference's `np.int` label
+    dtype (removed in NumPy 1.24) is int64 here."""
+    import numpy as np
+    from . import engine as _engine
+    if not models:
+        raise ValueError("detect needs at least one model")
+    channel_opts = channel_opts or models[0].channel_opts
+    if response_scale is None:
+        response_scale = [1] * len(models)
+    response_scale = np.array(response_scale, "f")
+    if response_scale.size != len(models):
+        raise ValueError("Wrong response_scale parameter")
+    channels._validate_image(image)
+    shrink, n_per_oct, smooth = channels.read_opts(channel_opts)
+    H, W = image.shape
+    eng = _engine.get_engine(H, W, image.dtype, shrink, n_per_oct, smooth, 1)
+    if eng.plan.n_levels == 0:
+        return concatenate([], ["scores", "label"])
+    eng.load_images(image)
+    eng.run_channels()
+    res = [m.scan_engine(eng) for m in models]
+    parts = []
+    for lv in range(eng.plan.n_levels):
+        for k, r in enumerate(res):
+            sel = r["level"] == lv
+            if not sel.any():
+                continue
+            b = Boxes(r["boxes"][sel])
+            b.set_field("scores", r["scores"][sel] * response_scale[k])
+            b.set_field("label", np.full(int(sel.sum()), k, dtype=np.int64))
+            parts.append(b)
+    if not parts:
+        out = Boxes(np.empty((0, 4), "f"))
+        out.set_field("scores", np.empty(0, "f"))
+        out.set_field("label", np.empty(0, np.int64))
+        return out
+    return concatenate(parts, ["scores", "label"])
+
+
 default_channel_opts = dict(shrink=2, n_per_oct=8, smooth=1, channels=channels.grad_hist)
 
-__all__ = ["Model", "DTree", "Boxes", "concatenate", "channels", "load", "load_model", "save", "save_model",
+__all__ = ["Model", "DTree", "Boxes", "concatenate", "channels", "detect", "load", "load_model", "save", "save_model",
            "default_channel_opts"]

@@ -147,8 +147,19 @@ class Model:
                         r=np.empty(0, np.int64), c=np.empty(0, np.int64), alive=np.zeros((0, T), np.int64),
                         scales=[])
         eng.load_images(image)
-        stt = eng.run(dm)
-        n_det = eng.ensure_capacity(dm)
+        eng.run_channels()
+        return self.scan_engine(eng)
+
+    def scan_engine(self, eng):
+        """Run this cascade over the channel pyramid already resident in `eng` (channels computed
+        by the caller: several models can share one pyramid, reference __init__.py:120-124).
+        Returns the same dict as detect_raw and updates n_loc / n_weak."""
+        m, n, Cc = self.shape
+        assert Cc == 4, f"Invalid number of channels. Expected {Cc} given 4."
+        dm = self.device_cascade()
+        T = len(self)
+        stt = eng.run_cascade(dm)
+        eng.ensure_capacity(dm)
         det = eng.sorted_detections()
         boxes, scores = eng.boxes(det, dm)
         alive = stt["alive"][0, :, :T].cpu().numpy().astype(np.int64).reshape(eng.plan.n_levels, T)
