@@ -86,6 +86,8 @@ def main():
                     help="HIP streams the steps are spread over (<= pool): consecutive steps work on different "
                          "images, so their kernels may overlap on the GPU like frames of a video pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
+                                                      "rehearse the multi-rank loop with several ranks on one GPU)")
     ap.add_argument("--stages", type=int, default=0, help="diagnostic: keep only the first N stages of the cascade")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--only", choices=["all", "channels", "cascade", "octaves"], default="all",
@@ -104,9 +106,13 @@ def main():
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    local_dev = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(args.backend)
 
     import waldboost_amd as wb
     from waldboost_amd import _native as nat
@@ -213,7 +219,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

@@ -31,8 +31,17 @@ class DetectionGatherer:
         self.NS, self.cap = detb.NS, detb.cap
         self.rows = detb.buf.shape[0]
         self.recv = torch.zeros((self.world * self.rows, 4), dtype=torch.int32, device=detb.buf.device)
+        # gloo has no all_gather for device tensors: a rehearsal of the multi-rank loop on one GPU
+        # (bench.py --backend gloo) stages through the host; the real path is RCCL ("nccl")
+        self._host_staged = detb.buf.is_cuda and dist.get_backend(group) == "gloo"
 
     def gather(self, detb, async_op=False):
+        if self._host_staged:
+            import torch
+            recv = torch.empty(self.recv.shape, dtype=torch.int32)
+            self.dist.all_gather_into_tensor(recv, detb.buf.cpu(), group=self.group)
+            self.recv.copy_(recv)
+            return None
         return self.dist.all_gather_into_tensor(self.recv, detb.buf, group=self.group, async_op=async_op)
 
     def merged(self, images_per_rank):
