@@ -67,13 +67,23 @@ typedef struct WbLevel {
     int32_t nw;
     int32_t u;        /* channel image size = nh/shrink, nw/shrink                  */
     int32_t v;
-    int32_t vp;       /* reserved (= v)                                             */
+    int32_t tap_off;  /* first entry of this level's resampling taps in the WbTap table:
+                         nh row taps, then nw column taps                           */
     int64_t src_off;  /* element offset of the octave in the per-image octave buffer;
                          octave 0 lives in the image buffer itself (src_off unused) */
     int64_t chn_off;  /* float offset of this level in the per-image channel buffer */
     double sy;        /* zoom step src_h/nh (fp64 division, as scipy zoom does)     */
     double sx;        /* src_w/nw                                                   */
 } WbLevel;            /* 64 bytes */
+
+/* One axis of the order-1 resample of an output coordinate k (scipy.ndimage.zoom, grid_mode=True,
+ * mode='mirror' -- what skimage.transform.resize runs for channels.py:132), built on the host in
+ * fp64 exactly as NI_ZoomShift does: cc = ((k + 0.5) * step) - 0.5; i0 = floor(cc);
+ * w0 = 1 - (cc - i0); w1 = 1 - w0; i1 = i0 + 1; indices mirror-mapped into the source. */
+typedef struct WbTap {
+    int32_t i0, i1;
+    double w0, w1;
+} WbTap; /* 24 bytes */
 
 /* One workgroup's tile: level index + tile coordinates (in tiles). */
 typedef struct WbTile {
@@ -124,6 +134,7 @@ int wb_octaves_launch(void *stream, const void *img, int dtype, int batch, int H
 /* All levels of all images: bilinear resize (fp64) -> Sobel gradients -> 4 oriented
  * channels (fp64 projection) -> shrink -> 3x3 smooth, fused per tile.
  *   levels   dev  WbLevel[n_levels];  tiles dev WbTile[n_tiles] (tile = wb_channels_tile)
+ *   taps     dev  WbTap table addressed by WbLevel.tap_off
  *   img/oct  as for wb_octaves_launch; both buffers must extend 16 bytes past their last element
  *            (source rows are fetched with 4-byte-aligned dword loads)
  *   cs_sn    HOST double[8]: cos(theta_k), k=0..3 then sin(theta_k) (channels.py:43-46)
@@ -132,7 +143,8 @@ int wb_octaves_launch(void *stream, const void *img, int dtype, int batch, int H
 int wb_channels_launch(void *stream, const void *img, int64_t img_stride, const void *oct,
                        int64_t oct_stride, int dtype, int batch, const WbLevel *levels, int n_levels,
                        const WbTile *tiles, int n_tiles, const uint32_t *minmax, int n_oct,
-                       int shrink, int smooth, const double *cs_sn, float *chn, int64_t chn_stride);
+                       const WbTap *taps, int shrink, int smooth, const double *cs_sn, float *chn,
+                       int64_t chn_stride);
 
 /* Build the device-side cascade from the reference's tree arrays (all HOST pointers).
  *   node_off  int32[n_stages+1]  first node of each stage's tree in the flat arrays

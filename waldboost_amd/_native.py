@@ -19,11 +19,12 @@ WB_DET_SHARDS = 64
 # numpy mirrors of the ABI structs (sizes asserted against the header's comments)
 LEVEL_DTYPE = np.dtype([
     ("oct", "<i4"), ("src_h", "<i4"), ("src_w", "<i4"), ("nh", "<i4"), ("nw", "<i4"),
-    ("u", "<i4"), ("v", "<i4"), ("vp", "<i4"), ("src_off", "<i8"), ("chn_off", "<i8"),
+    ("u", "<i4"), ("v", "<i4"), ("tap_off", "<i4"), ("src_off", "<i8"), ("chn_off", "<i8"),
     ("sy", "<f8"), ("sx", "<f8")], align=True)
+TAP_DTYPE = np.dtype([("i0", "<i4"), ("i1", "<i4"), ("w0", "<f8"), ("w1", "<f8")], align=True)
 TILE_DTYPE = np.dtype([("level", "<i4"), ("ty", "<u2"), ("tx", "<u2")], align=True)
 DET_DTYPE = np.dtype([("image", "<i4"), ("level", "<i4"), ("r", "<u2"), ("c", "<u2"), ("score", "<f4")], align=True)
-assert LEVEL_DTYPE.itemsize == 64 and TILE_DTYPE.itemsize == 8 and DET_DTYPE.itemsize == 16
+assert LEVEL_DTYPE.itemsize == 64 and TILE_DTYPE.itemsize == 8 and DET_DTYPE.itemsize == 16 and TAP_DTYPE.itemsize == 24
 
 
 class WbModelInfo(C.Structure):
@@ -40,7 +41,7 @@ SYMBOLS = {
     "wb_octaves_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, C.c_int64,
                                     C.POINTER(C.c_int64), C.c_int, _P]),
     "wb_channels_launch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int,
-                                     _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P, C.c_int64]),
+                                     _P, C.c_int, _P, C.c_int, C.c_int, C.POINTER(C.c_double), _P, C.c_int64]),
     "wb_model_create": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "wb_model_destroy": (C.c_int, [_P]),
     "wb_model_info": (C.c_int, [_P, C.POINTER(WbModelInfo)]),

@@ -25,6 +25,7 @@ struct ChanArgs {
     const WbLevel *levels;
     const WbTile *tiles;
     const uint32_t *minmax;
+    const WbTap *taps;
     int n_oct;
     float *chn;
     int64_t chn_stride;
@@ -33,30 +34,7 @@ struct ChanArgs {
     int dbg;             // diagnostics (WB_CHAN_DBG): 1 = stop after step 1, 2 = after step 2, 4 = skip the stores
 };
 
-struct Tap {          // one axis of the bilinear resample (scipy NI_ZoomShift, order 1)
-    int i0, i1;       // source indices (mirror-mapped)
-    double w0, w1;    // w0 = 1 - frac, w1 = 1 - w0
-};
-
-__device__ inline int mirror_idx(int i, int n) {
-    // scipy 'mirror' (no edge repeat); only ever reached with weight 0 when down-scaling
-    if (i < 0) i = -i;
-    if (i >= n) i = 2 * (n - 1) - i;
-    return i < 0 ? 0 : i;
-}
-
-__device__ inline Tap make_tap(int k, double step, int n_in) {
-    double cc = (((double)k + 0.5) * step) - 0.5;
-    double fl = floor(cc);
-    double x = cc - fl;
-    Tap t;
-    t.w0 = 1.0 - x;
-    t.w1 = 1.0 - t.w0;
-    int i0 = (int)fl;
-    t.i0 = mirror_idx(i0, n_in);
-    t.i1 = mirror_idx(i0 + 1, n_in);
-    return t;
-}
+typedef WbTap Tap;   // one axis of the bilinear resample (scipy NI_ZoomShift, order 1), host-built table
 
 // scipy's order-1 resample of one output pixel: fp64, taps and additions in NI_ZoomShift's order
 __device__ inline double resample_f64(double v00, double v01, double v10, double v11, const Tap &tr, const Tap &tc) {
@@ -187,6 +165,8 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
     const double mn = Src<T>::lo(~mm[0]), mx = Src<T>::lo(mm[1]);   // mm[0] holds max(~key)
 
     const int ry0 = S * (u0 - HS) - 1, rx0 = S * (v0 - HS) - 1;
+    const Tap *__restrict__ rtap = a.taps + L.tap_off;      // row taps [nh], then column taps [nw]
+    const Tap *__restrict__ ctap = rtap + L.nh;
     // ---- step 1: bilinear resample of the tile (+ Sobel halo) into R, cast back to the image dtype.
     //      One tile row per wave at a time: the row's taps are wave-uniform (scalar registers,
     //      scalar row base pointers), the column taps of a lane's NCS columns live in registers,
@@ -211,8 +191,8 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
         int yl = ry0 + RH - 1; yl = yl < 0 ? 0 : (yl > L.nh - 1 ? L.nh - 1 : yl);
         int xf = rx0 < 0 ? 0 : (rx0 > L.nw - 1 ? L.nw - 1 : rx0);
         int xl = rx0 + RW - 1; xl = xl < 0 ? 0 : (xl > L.nw - 1 ? L.nw - 1 : xl);
-        const Tap t_yf = make_tap(yf, L.sy, L.src_h), t_yl = make_tap(yl, L.sy, L.src_h);
-        const Tap t_xf = make_tap(xf, L.sx, L.src_w), t_xl = make_tap(xl, L.sx, L.src_w);
+        const Tap t_yf = rtap[yf], t_yl = rtap[yl];
+        const Tap t_xf = ctap[xf], t_xl = ctap[xl];
         r_lo = t_yf.i0 < t_yf.i1 ? t_yf.i0 : t_yf.i1;
         c_lo = t_xf.i0 < t_xf.i1 ? t_xf.i0 : t_xf.i1;
         const int r_hi = t_yl.i0 > t_yl.i1 ? t_yl.i0 : t_yl.i1;
@@ -255,7 +235,7 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
             for (int c = 0; c < NCS; ++c) {
                 int x = rx0 + lane + 64 * c;
                 x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
-                tc[c] = make_tap(x, L.sx, L.src_w);
+                tc[c] = ctap[x];
                 ci0[c] = tc[c].i0 - c_lo;
                 ci1[c] = tc[c].i1 - c_lo;
                 wc0f[c] = (float)tc[c].w0;
@@ -265,7 +245,7 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
             for (int k = wave; k < RH; k += 4) {
                 int y = ry0 + k;
                 y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
-                const Tap tr = make_tap(__builtin_amdgcn_readfirstlane(y), L.sy, L.src_h);
+                const Tap tr = rtap[__builtin_amdgcn_readfirstlane(y)];
                 const int i0 = __builtin_amdgcn_readfirstlane(tr.i0), i1 = __builtin_amdgcn_readfirstlane(tr.i1);
                 // byte offset of column c_lo inside the row's LDS image = its misalignment in memory
                 const int o0 = (i0 - r_lo) * PPITCH + (int)((base + (uintptr_t)((int64_t)i0 * L.src_w + c_lo)) & 3);
@@ -290,7 +270,7 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
         for (int c = 0; c < NCS; ++c) {
             int x = rx0 + lane + 64 * c;
             x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
-            tc[c] = make_tap(x, L.sx, L.src_w);
+            tc[c] = ctap[x];
             wc0f[c] = (float)tc[c].w0;
             wc1f[c] = (float)tc[c].w1;
         }
@@ -306,7 +286,7 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
                 k = k < RH ? k : RH - 1;                                  // clamped, unconditional loads
                 int y = ry0 + k;
                 y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
-                tr[rb] = make_tap(__builtin_amdgcn_readfirstlane(y), L.sy, L.src_h);
+                tr[rb] = rtap[__builtin_amdgcn_readfirstlane(y)];
                 const T *r0 = src + (int64_t)__builtin_amdgcn_readfirstlane(tr[rb].i0) * L.src_w;
                 const T *r1 = src + (int64_t)__builtin_amdgcn_readfirstlane(tr[rb].i1) * L.src_w;
 #pragma unroll
@@ -345,7 +325,7 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
             int y = ry0 + k, x = rx0 + q;
             y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
             x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
-            const Tap tr = make_tap(y, L.sy, L.src_h), tc = make_tap(x, L.sx, L.src_w);
+            const Tap tr = rtap[y], tc = ctap[x];
             const T *r0 = src + (int64_t)tr.i0 * L.src_w;
             const T *r1 = src + (int64_t)tr.i1 * L.src_w;
             const T a00 = r0[tc.i0], a01 = r0[tc.i1], a10 = r1[tc.i0], a11 = r1[tc.i1];
@@ -528,9 +508,9 @@ extern "C" int wb_channels_tile(int shrink, int *tile_u, int *tile_v) {
 extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_stride, const void *oct,
                                   int64_t oct_stride, int dtype, int batch, const WbLevel *levels,
                                   int n_levels, const WbTile *tiles, int n_tiles, const uint32_t *minmax,
-                                  int n_oct, int shrink, int smooth, const double *cs_sn, float *chn,
-                                  int64_t chn_stride) {
-    WB_REQUIRE(img && levels && tiles && minmax && cs_sn && chn, "wb_channels_launch: null pointer");
+                                  int n_oct, const WbTap *taps, int shrink, int smooth, const double *cs_sn,
+                                  float *chn, int64_t chn_stride) {
+    WB_REQUIRE(img && levels && tiles && minmax && taps && cs_sn && chn, "wb_channels_launch: null pointer");
     WB_REQUIRE(batch >= 1 && n_levels >= 1 && n_tiles >= 1, "wb_channels_launch: empty launch");
     WB_REQUIRE(batch <= 65535, "wb_channels_launch: batch %d exceeds grid.y limit", batch);
     WB_REQUIRE(smooth == 0 || smooth == 1, "wb_channels_launch: smooth must be 0 or 1");
@@ -543,6 +523,7 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
     a.levels = levels;
     a.tiles = tiles;
     a.minmax = minmax;
+    a.taps = taps;
     a.n_oct = n_oct;
     a.chn = chn;
     a.chn_stride = chn_stride;

@@ -158,6 +158,8 @@ class PyramidEngine:
         self.chn_stride = int(total)
         self.level_np = table
         self.levels = torch.from_numpy(table.view(np.uint8).copy()).to(dev) if p.n_levels else None
+        taps, _ = p.tap_table()
+        self.taps = torch.from_numpy(taps.view(np.uint8).copy()).to(dev)
         tiles = p.chan_tiles()
         self.n_chan_tiles = int(tiles.size)
         self.chan_tiles = torch.from_numpy(tiles.view(np.uint8).copy()).to(dev) if tiles.size else None
@@ -218,7 +220,7 @@ class PyramidEngine:
         nat.check(self.lib.wb_channels_launch(nat.stream_ptr(), nat.ptr(self.img), p.H * p.W, nat.ptr(self.oct),
                                               p.oct_total, self.wb_dtype, self.batch, nat.ptr(self.levels),
                                               p.n_levels, nat.ptr(self.chan_tiles), self.n_chan_tiles,
-                                              nat.ptr(self.minmax), max(p.n_oct, 1), p.shrink, p.smooth,
+                                              nat.ptr(self.minmax), max(p.n_oct, 1), nat.ptr(self.taps), p.shrink, p.smooth,
                                               self.cs_sn.ctypes.data_as(C.POINTER(C.c_double)), nat.ptr(self.chn),
                                               self.chn_stride), "wb_channels_launch")
 

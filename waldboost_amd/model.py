@@ -110,6 +110,7 @@ class Model:
         u, v, ch_image = X.shape
         m, n, ch_cls = self.shape
         assert ch_image == ch_cls, f"Invalid number of channels. Expected {ch_cls} given {ch_image}."
+        _require_float32(X)
         dm = self.device_cascade()
         eng = _SingleLevel.get(u, v, ch_image)
         eng.load(X)
@@ -219,6 +220,14 @@ class Model:
         return Model.from_proto(proto)
 
 
+def _require_float32(X):
+    """Channel images are float32 (what channel_pyramid yields).  The reference would compare a
+    float64 X with its float32 thresholds in float64; silently casting X would change results."""
+    dt = getattr(X, "dtype", None)
+    if str(dt).replace("torch.", "") != "float32":
+        raise TypeError(f"channel image must be float32 (as produced by channel_pyramid), got {dt}")
+
+
 class _SingleLevel:
     """Device state for Model.predict_on_image on a caller-supplied HWC channel image."""
     _cache = {}
@@ -242,7 +251,7 @@ class _SingleLevel:
             raise ValueError("channel image larger than 65535 pixels per side")
         self.u, self.v, self.C = u, v, C
         t = np.zeros(1, nat.LEVEL_DTYPE)
-        t[0]["u"], t[0]["v"], t[0]["vp"], t[0]["chn_off"] = u, v, v, 0
+        t[0]["u"], t[0]["v"], t[0]["chn_off"] = u, v, 0
         self.levels = torch.from_numpy(t.view(np.uint8).copy()).to(self.dev)
         self.X = torch.empty((max(u * v * C, 1),), dtype=torch.float32, device=self.dev)
         self.detb = _engine.DetBuffer(1 << 10, self.dev)

@@ -14,7 +14,7 @@ import math
 
 import numpy as np
 
-from ._native import LEVEL_DTYPE, TILE_DTYPE
+from ._native import LEVEL_DTYPE, TAP_DTYPE, TILE_DTYPE
 
 N_CHANNELS = 4          # grad_hist with n_bins=4 (reference channels.py:40)
 CHAN_TILES = {1: (16, 64), 2: (16, 64), 4: (8, 32)}   # must match wb_channels_tile()
@@ -71,7 +71,6 @@ class PyramidPlan:
                     levels.append(dict(oct=o, h=h, w=w, nh=nh, nw=nw, scale=real_scale / shrink))
         for lv in levels:
             lv["u"], lv["v"] = lv["nh"] // shrink, lv["nw"] // shrink
-            lv["vp"] = lv["v"]
             if lv["u"] >= 65536 or lv["v"] >= 65536:
                 raise ValueError("channel image larger than 65535 pixels per side")
         self.levels = levels
@@ -89,15 +88,47 @@ class PyramidPlan:
             acc += N_CHANNELS * lv["u"] * lv["v"]
         return offs, max(acc, 4)
 
+    @staticmethod
+    def axis_taps(n_in, n_out):
+        """Resampling taps of one axis (WbTap): scipy NI_ZoomShift with grid_mode=True, order 1,
+        mode='mirror', in fp64 with scipy's operation order."""
+        t = np.zeros(n_out, TAP_DTYPE)
+        step = np.float64(n_in) / np.float64(n_out)
+        cc = ((np.arange(n_out, dtype=np.float64) + 0.5) * step) - 0.5
+        fl = np.floor(cc)
+        x = cc - fl
+        t["w0"] = 1.0 - x
+        t["w1"] = 1.0 - t["w0"]
+        i0 = fl.astype(np.int64)
+
+        def mirror(i):
+            i = np.abs(i)
+            i = np.where(i >= n_in, 2 * (n_in - 1) - i, i)
+            return np.maximum(i, 0)
+
+        t["i0"], t["i1"] = mirror(i0), mirror(i0 + 1)
+        return t
+
+    def tap_table(self):
+        """All levels' taps back to back (rows then columns of each level) and the level offsets."""
+        parts, offs, acc = [], [], 0
+        for lv in self.levels:
+            offs.append(acc)
+            parts += [self.axis_taps(lv["h"], lv["nh"]), self.axis_taps(lv["w"], lv["nw"])]
+            acc += lv["nh"] + lv["nw"]
+        return (np.concatenate(parts) if parts else np.zeros(1, TAP_DTYPE)), offs
+
     def level_table(self):
         if self._table is None:
             offs, total = self.chn_offsets()
+            _, tap_offs = self.tap_table()
             t = np.zeros(self.n_levels, LEVEL_DTYPE)
             for i, lv in enumerate(self.levels):
+                t[i]["tap_off"] = tap_offs[i]
                 t[i]["oct"] = lv["oct"]
                 t[i]["src_h"], t[i]["src_w"] = lv["h"], lv["w"]
                 t[i]["nh"], t[i]["nw"] = lv["nh"], lv["nw"]
-                t[i]["u"], t[i]["v"], t[i]["vp"] = lv["u"], lv["v"], lv["vp"]
+                t[i]["u"], t[i]["v"] = lv["u"], lv["v"]
                 t[i]["src_off"] = self.oct_off[lv["oct"]]
                 t[i]["chn_off"] = offs[i]
                 # scipy zoom recomputes the step from the integer shapes in fp64

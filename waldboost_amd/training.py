@@ -68,6 +68,8 @@ class DTree:
         if rs.size == 0:
             return np.empty(0, np.float32)
         u, v, C = X.shape
+        if str(getattr(X, "dtype", None)).replace("torch.", "") != "float32":
+            raise TypeError(f"channel image must be float32 (as produced by channel_pyramid), got {getattr(X, 'dtype', None)}")
         fmax = self.feature[self.node].max(axis=0) if self.node.any() else np.zeros(3, np.int64)
         if rs.min() < 0 or cs.min() < 0 or rs.max() + int(fmax[0]) >= u or cs.max() + int(fmax[1]) >= v or int(fmax[2]) >= C:
             raise IndexError("window feature outside the channel image")
