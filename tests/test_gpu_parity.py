@@ -321,3 +321,38 @@ def test_multi_model_detect_shares_one_pyramid():
         assert M.n_loc == r["n_loc"] and M.n_weak == r["n_weak"]
     with pytest.raises(ValueError):
         wb.detect(img, *models, response_scale=[1.0])
+
+
+# ------------------------------------------------------------------------------ batches / configs
+def test_detect_batch_equals_per_image_detect():
+    imgs = np.stack([synth_image(210, 290, 600 + b) for b in range(5)])
+    M = random_model(42, 30, 2)
+    per = []
+    for b in range(5):
+        r = M.detect_raw(imgs[b])
+        per.append(r)
+    n_loc1, n_weak1 = M.n_loc, M.n_weak
+    M.reset()
+    res = M.detect_batch_raw(imgs)
+    assert (M.n_loc, M.n_weak) == (n_loc1, n_weak1)
+    for b in range(5):
+        sel = res["image"] == b
+        assert np.array_equal(res["level"][sel], per[b]["level"]) and np.array_equal(res["r"][sel], per[b]["r"])
+        assert np.array_equal(res["c"][sel], per[b]["c"]) and np.array_equal(bits(res["scores"][sel]), bits(per[b]["scores"]))
+        assert np.array_equal(bits(res["boxes"][sel]), bits(per[b]["boxes"]))
+        assert np.array_equal(res["alive"][b], per[b]["alive"])
+    bxs = M.detect_batch(imgs)
+    assert [len(b) for b in bxs] == [int((res["image"] == b).sum()) for b in range(5)]
+
+
+def test_config5_4k_shrink4_256_stages_vs_oracle():
+    """BASELINE configs[4]: 3840x2160, shrink=4 (extension: the reference asserts shrink in [1,2]),
+    n_per_oct=12, 256-stage depth-2 cascade, survival ~1e-4 -- against the oracle at full size."""
+    M = wb.load(os.path.join(GOLDEN, "models", "cfg5_d2_T256.pb"))
+    assert len(M) == 256 and M.channel_opts["shrink"] == 4 and M.channel_opts["n_per_oct"] == 12
+    img = synth_image(2160, 3840, 0)
+    res = M.detect_raw(img)
+    ref = oracle_detect(M, img)
+    assert ref["n_loc"] == 4435665 == M.n_loc and ref["alive"].shape == (108, 256)
+    assert_same_detections(res, ref)
+    assert M.n_weak == ref["n_weak"]

@@ -64,3 +64,45 @@ class DetectionGatherer:
         out = np.concatenate(parts) if parts else np.zeros(0, DET_DTYPE)
         order = np.lexsort((out["c"], out["r"], out["level"], out["image"]))
         return out[order]
+
+
+def detect_sharded(model, images, group=None):
+    """Detect on a batch that is split over the ranks of `group` (one process per GPU): every rank
+    passes the SAME global batch [B,H,W] (host array) and scans its contiguous shard; the detection
+    records of all ranks are then gathered with one collective.  Returns, on every rank, the merged
+    records (numpy structured array of WbDet with GLOBAL image indices, reference order) and the
+    per-image alive counts of the local shard."""
+    import torch.distributed as dist
+    from . import engine as _engine
+    from . import channels as _channels
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = int(images.shape[0])
+    lo, hi = shard_range(B, rank, world)
+    counts = [shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world)]
+    nb = max(counts)                                   # every rank runs the same (padded) batch size
+    shrink, n_per_oct, smooth = _channels.read_opts(model.channel_opts)
+    H, W = int(images.shape[1]), int(images.shape[2])
+    eng = _engine.get_engine(H, W, images.dtype, shrink, n_per_oct, smooth, nb)
+    local = np.zeros((nb, H, W), images.dtype)
+    local[: hi - lo] = images[lo:hi]
+    dm = model.device_cascade()
+    eng.load_images(local)
+    stt = eng.run(dm)
+    eng.ensure_capacity(dm)
+    g = DetectionGatherer(eng.detb, group)
+    g.gather(eng.detb)
+    merged = g.merged([nb] * world)                    # image index = rank * nb + local index
+    # drop the padding images and renumber to the global batch
+    keep = np.zeros(merged.size, bool)
+    glob = np.zeros(merged.size, np.int32)
+    for r in range(world):
+        rlo = shard_range(B, r, world)[0]
+        sel = (merged["image"] >= r * nb) & (merged["image"] < r * nb + counts[r])
+        keep |= sel
+        glob[sel] = merged["image"][sel] - r * nb + rlo
+    out = merged[keep].copy()
+    out["image"] = glob[keep]
+    order = np.lexsort((out["c"], out["r"], out["level"], out["image"]))
+    T = len(model)
+    alive = stt["alive"][: hi - lo, :, :T].cpu().numpy().astype(np.int64)
+    return out[order], alive

@@ -170,6 +170,51 @@ class Model:
         return dict(boxes=boxes.cpu().numpy(), scores=scores.cpu().numpy(), level=d["level"].copy(),
                     r=d["r"].astype(np.int64), c=d["c"].astype(np.int64), alive=alive, scales=list(eng.plan.scales))
 
+    def detect_batch(self, images):
+        """detect() on a batch: `images` is [B,H,W] (ndarray or device tensor) of one shape and dtype;
+        the whole batch goes through each kernel in one launch.  Returns a list of B Boxes (same
+        content and order as B calls of detect) and updates n_loc / n_weak."""
+        res = self.detect_batch_raw(images)
+        out = []
+        for b in range(res["batch"]):
+            sel = res["image"] == b
+            bx = Boxes(res["boxes"][sel])
+            bx.set_field("scores", res["scores"][sel])
+            out.append(bx)
+        return out
+
+    def detect_batch_raw(self, images):
+        """All detections of a batch as flat arrays (image, level, r, c, boxes, scores, alive[B,L,T])."""
+        if getattr(images, "ndim", None) != 3 and (not hasattr(images, "dim") or images.dim() != 3):
+            raise ValueError("images must have 3 dimensions [B,H,W]")
+        B, H, W = (int(x) for x in images.shape)
+        dtype = images.dtype if isinstance(images, np.ndarray) else {"torch.uint8": np.uint8, "torch.float32": np.float32}.get(str(images.dtype))
+        if dtype is None:
+            raise NotImplementedError(f"image dtype {images.dtype} has no HIP kernel (uint8 and float32 are supported)")
+        shrink, n_per_oct, smooth = _channels.read_opts(self.channel_opts)
+        m, n, Cc = self.shape
+        assert Cc == 4, f"Invalid number of channels. Expected {Cc} given 4."
+        dm = self.device_cascade()
+        T = len(self)
+        eng = _engine.get_engine(H, W, dtype, shrink, n_per_oct, smooth, B)
+        L = eng.plan.n_levels
+        if L == 0:
+            return dict(batch=B, image=np.empty(0, np.int32), level=np.empty(0, np.int32), r=np.empty(0, np.int64),
+                        c=np.empty(0, np.int64), boxes=np.empty((0, 4), "f"), scores=np.empty(0, "f"),
+                        alive=np.zeros((B, 0, T), np.int64), scales=[])
+        eng.load_images(images)
+        stt = eng.run(dm)
+        eng.ensure_capacity(dm)
+        det = eng.sorted_detections()
+        boxes, scores = eng.boxes(det, dm)
+        alive = stt["alive"][:, :, :T].cpu().numpy().astype(np.int64).reshape(B, L, T)
+        self.n_loc += B * eng.plan.n_loc(m, n)
+        self.n_weak += int(alive.sum())
+        d = det.cpu().numpy().view(nat.DET_DTYPE).reshape(-1)
+        return dict(batch=B, image=d["image"].copy(), level=d["level"].copy(), r=d["r"].astype(np.int64),
+                    c=d["c"].astype(np.int64), boxes=boxes.cpu().numpy(), scores=scores.cpu().numpy(), alive=alive,
+                    scales=list(eng.plan.scales))
+
     def predict(self, X):
         raise NotImplementedError("Model.predict (per-sample mode used by training) is outside the detection hot path")
 
