@@ -57,7 +57,7 @@ void fill(const TreeView &t, int node, int ci, int d, int D, int rows, int pitch
         return;
     }
     int fr = t.feature[node * 3 + 0], fc = t.feature[node * 3 + 1], ch = t.feature[node * 3 + 2];
-    off[ci] = (ch * rows + fr) * pitch + fc;
+    off[ci] = ((ch * rows + fr) * pitch + fc) * 4;       // byte offset inside the LDS tile
     thr[ci] = t.threshold[node];
     fill(t, t.left[node], 2 * ci + 1, d + 1, D, rows, pitch, off, thr, pred);
     fill(t, t.right[node], 2 * ci + 2, d + 1, D, rows, pitch, off, thr, pred);

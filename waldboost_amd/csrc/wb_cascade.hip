@@ -85,25 +85,27 @@ template <int D> struct Stage {
         for (int i = 0; i < NL; ++i) pred[i] = as_f(sp[2 * NI + i]);
         theta = as_f(sp[2 * NI + NL]);
     }
-    // walk the complete depth-D tree for the window whose origin is tile[base]
+    // walk the complete depth-D tree for the window whose origin is at BYTE offset `base` of the
+    // LDS tile (offsets in the records are bytes too: one v_add per gather)
     __device__ inline float eval(const float *tile, int base) const {
+        const char *t8 = reinterpret_cast<const char *>(tile);
         bool right[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) right[d] = false;
         {
-            float v = tile[base + off[0]];
+            float v = *reinterpret_cast<const float *>(t8 + (base + off[0]));
             right[0] = !(v <= thr[0]);                 // NaN goes right, like the reference's `<=`
         }
         if constexpr (D > 1) {
             int o = Sel<2, int>::get(off + 1, right);
             float th = Sel<2, float>::get(thr + 1, right);
-            float v = tile[base + o];
+            float v = *reinterpret_cast<const float *>(t8 + (base + o));
             right[1] = !(v <= th);
         }
         if constexpr (D > 2) {
             int o = Sel<4, int>::get(off + 3, right);
             float th = Sel<4, float>::get(thr + 3, right);
-            float v = tile[base + o];
+            float v = *reinterpret_cast<const float *>(t8 + (base + o));
             right[2] = !(v <= th);
         }
         return Sel<NL, float>::get(pred, right);
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     for (int j = 0; j < RPW; ++j) {
         hs[j] = 0.f;
         live[j] = (c0 + lane < nc) && (r0 + wr + j < nr);
-        base[j] = (wr + j) * pitch + lane;
+        base[j] = ((wr + j) * pitch + lane) * 4;
     }
     const int tA = T < S0 ? T : S0;
     for (int t = 0; t < tA; t += G) {
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
                 float h = hs[j] + p[g][j];
-                hs[j] = live[j] ? h : hs[j];
+                hs[j] = h;                                   // (a dead window's sum is never read again)
                 live[j] = live[j] && (!rejects || h >= st[g].theta);
             }
         }
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
                 uint2 e = alive ? queue[i] : make_uint2(0u, 0u);
                 int pos = (int)e.x;
                 float h = __uint_as_float(e.y);
-                int wbase = (pos >> 6) * pitch + (pos & 63);
+                int wbase = ((pos >> 6) * pitch + (pos & 63)) * 4;
                 for (int t = t_begin; t < t_end; t += G) {
                     if (__ballot(alive) == 0ull) break;
                     Stage<D> st[G];
@@ -292,9 +294,8 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
                         if (t + g >= t_end) break;
                         int cnt = __popcll(__ballot(alive));
                         if (cnt && lane == 0) atomicAdd(&hist[t + g], (uint32_t)cnt);
-                        float h2 = h + p[g];
-                        h = alive ? h2 : h;
-                        alive = alive && (st[g].theta == -INFINITY || h2 >= st[g].theta);
+                        h = h + p[g];                        // (a dead window's sum is never read again)
+                        alive = alive && (st[g].theta == -INFINITY || h >= st[g].theta);
                     }
                 }
                 unsigned long long mask = __ballot(alive);
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         for (int i = 0; i < n_q; ++i) {
             const uint2 e = queue[i];                            // same entry in every lane
             const int pos = (int)e.x;
-            const int wbase = (pos >> 6) * pitch + (pos & 63);
+            const int wbase = ((pos >> 6) * pitch + (pos & 63)) * 4;
             const float p = st.eval(tile, wbase);
             // Replay in stage order: lane k accumulates p_0 .. p_k one after the other -- the same
             // additions in the same order as the reference's running `hs +=` -- so it ends up

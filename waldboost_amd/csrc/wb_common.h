@@ -49,7 +49,7 @@ __host__ __device__ inline float wb_key_f32(uint32_t k) {
 #define WB_CASC_MAX_DEPTH 3
 
 // The canonical stage record the cascade kernels read with scalar loads:
-//   int   off[NI]   LDS float offset of each internal node's feature (BFS order)
+//   int   off[NI]   LDS byte offset of each internal node's feature (BFS order)
 //   float thr[NI]
 //   float pred[NL]  leaf predictions, left to right
 //   float theta
