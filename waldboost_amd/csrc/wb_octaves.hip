@@ -39,7 +39,8 @@ template <> __device__ inline float pool4<float>(float a, float b, float c, floa
     return (((a + b) + c) + d) * 0.25f;
 }
 
-// workgroup reduction of (lo-as-~key max, hi max) -> two atomics by thread 0
+// workgroup reduction of (lo-as-~key max, hi max) -> two atomics by thread 0 (one pair per wave was
+// measured 2x slower at batch 1: hundreds of atomics queue up on each octave's two words)
 __device__ inline void block_minmax_commit(uint32_t nlo, uint32_t hi, uint32_t *red, uint32_t *mm) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -74,7 +75,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void octaves_block_kernel(const T *img, int64_t img_stride, T *oct, int64_t oct_stride,
                                                             OctDims d, int n_oct, int blocks_x, uint32_t *minmax) {
     constexpr int OB = Blk<T>::OB, OB_LEVELS = Blk<T>::LEVELS;
-    __shared__ T bufA[OB * OB];
+    __shared__ __attribute__((aligned(16))) T bufA[OB * OB];
     __shared__ T bufB[(OB / 2) * (OB / 2)];
     __shared__ uint32_t red[8];
 
@@ -85,21 +86,77 @@ __global__ __launch_bounds__(256) void octaves_block_kernel(const T *img, int64_
     T *obase = oct + (int64_t)b * oct_stride;
     uint32_t *mm = minmax + (int64_t)b * n_oct * 2;
 
-    // ---- octave 0 block -> LDS, with its min/max (all pixels, odd tails included)
+    // ---- octave 0 block -> LDS, with its min/max (all pixels, odd tails included).  Loads are
+    //      unconditional (clamped addresses) and issued 8 at a time; bytes travel as dwords when the
+    //      rows are 4-byte aligned.
     const int H = d.h[0], W = d.w[0];
     const int y0 = by * OB, x0 = bx * OB;
     uint32_t nlo = 0u, hi = 0u;
-    for (int i = tid; i < OB * OB; i += 256) {
-        int r = i / OB, c = i - r * OB;
-        int y = y0 + r, x = x0 + c;
-        T v = T(0);
-        if (y < H && x < W) {
-            v = src[(int64_t)y * W + x];
-            uint32_t k = PixKey<T>::key(v);
-            nlo = (~k) > nlo ? (~k) : nlo;
-            hi = k > hi ? k : hi;
+    constexpr int U = 8;
+    if (sizeof(T) == 1 && (W & 3) == 0 && (img_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0) {
+        constexpr int DW = OB / 4;                                   // dwords per block row
+        const uint32_t *src32 = reinterpret_cast<const uint32_t *>(src);
+        uint32_t *lds32 = reinterpret_cast<uint32_t *>(bufA);
+        const int wdw = W >> 2;
+        for (int i0 = tid; i0 < OB * DW; i0 += 256 * U) {
+            uint32_t v[U];
+            bool ok[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                int i = i0 + k * 256;
+                i = i < OB * DW ? i : OB * DW - 1;
+                int r = i / DW, c = i - r * DW;
+                int y = y0 + r, xd = (x0 >> 2) + c;
+                ok[k] = (y < H) && (xd < wdw);
+                y = y < H ? y : H - 1;
+                xd = xd < wdw ? xd : wdw - 1;
+                v[k] = src32[(int64_t)y * wdw + xd];
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                int i = i0 + k * 256;
+                if (i < OB * DW) {
+                    uint32_t w = ok[k] ? v[k] : 0u;
+                    lds32[i] = w;
+                    if (ok[k]) {
+#pragma unroll
+                        for (int bb = 0; bb < 4; ++bb) {
+                            uint32_t kk = (w >> (8 * bb)) & 255u;
+                            nlo = (~kk) > nlo ? (~kk) : nlo;
+                            hi = kk > hi ? kk : hi;
+                        }
+                    }
+                }
+            }
         }
-        bufA[i] = v;
+    } else {
+        for (int i0 = tid; i0 < OB * OB; i0 += 256 * U) {
+            T v[U];
+            bool ok[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                int i = i0 + k * 256;
+                i = i < OB * OB ? i : OB * OB - 1;
+                int r = i / OB, c = i - r * OB;
+                int y = y0 + r, x = x0 + c;
+                ok[k] = (y < H) && (x < W);
+                y = y < H ? y : H - 1;
+                x = x < W ? x : W - 1;
+                v[k] = src[(int64_t)y * W + x];
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                int i = i0 + k * 256;
+                if (i < OB * OB) {
+                    bufA[i] = ok[k] ? v[k] : T(0);
+                    if (ok[k]) {
+                        uint32_t kk = PixKey<T>::key(v[k]);
+                        nlo = (~kk) > nlo ? (~kk) : nlo;
+                        hi = kk > hi ? kk : hi;
+                    }
+                }
+            }
+        }
     }
     __syncthreads();
     block_minmax_commit(nlo, hi, red, mm);
