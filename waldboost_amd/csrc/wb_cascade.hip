@@ -13,13 +13,15 @@
 //     and the rejection tests are sequential);
 //   * phase A runs the first stages with RPW windows per lane; survivors are compacted with
 //     wave ballot + mbcnt into the wave's own LDS queue; phase B re-packs them densely for
-//     geometrically growing stage segments, compacting in place after each segment;
+//     geometrically growing stage segments, compacting in place after each segment, and pools
+//     the survivors of the whole workgroup once, at stage 8, so that a few waves hold full
+//     chunks of 64 and the rest retire;
 //   * stage-parallel tail: once a wave is down to a handful of windows (about 1e-3 of the
 //     windows of the benchmark cascade reach stage 32, with ~100 stages to go) the roles flip:
 //     one window at a time, 64 stages AT ONCE, one stage per lane (per-lane stage records,
 //     gathers from the same LDS tile); the fp32 accumulation and the rejection tests are then
-//     replayed in stage order -- lane i adds p_0 .. p_i one after the other, exactly the
-//     reference's running sum -- so a nearly empty wave no longer walks 100 stages serially
+//     replayed in stage order (a DPP wave_shr:1 ripple: lane i ends up with ((h+p_0)+p_1)+...+p_i,
+//     exactly the reference's running sum) -- so a nearly empty wave no longer walks 100 stages serially
 //     while the workgroup's LDS tile sits idle;
 //   * the windows alive after the last stage stay in the wave's queue; one thread reserves room
 //     for the whole workgroup with ONE atomic on one of WB_DET_SHARDS counters and the waves
