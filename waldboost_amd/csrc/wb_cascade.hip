@@ -135,7 +135,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     constexpr int TR = RPW * WAVES;
     constexpr int SD = WB_STAGE_DWORDS(D);
     constexpr int G = GroupSize<D>::G;
-    constexpr int S0 = 4;                                  // stages in phase A (multiple of G)
+    constexpr int S0 = 8;                                  // stages in phase A (multiple of G; 4 and 12 measured slower)
     constexpr int SPAR_FROM = 16, SPAR_MAX = 8;            // when a wave flips to the stage-parallel tail (see run_segments)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
