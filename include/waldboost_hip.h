@@ -152,7 +152,8 @@ int wb_channels_launch(void *stream, const void *img, int64_t img_stride, const 
  *   threshold float[n_nodes], left/right int8[n_nodes] (-1 on leaves), prediction float[n_nodes]
  *   theta     float[n_stages]    rejection thresholds, -inf = stage never rejects
  * Trees must have parent index < child index (the order the reference walks them in,
- * training.py:88).  Returns WB_ERR_UNSUPPORTED for trees deeper than 3. */
+ * training.py:88).  Trees up to depth 3 run in the LDS-tiled kernel; deeper ones in a generic
+ * node-walk kernel (correct, not tuned). */
 int wb_model_create(int n_stages, const int32_t *node_off, const uint8_t *feature,
                     const float *threshold, const int8_t *left, const int8_t *right,
                     const float *prediction, const float *theta, int m, int n, int C,

@@ -356,3 +356,48 @@ def test_config5_4k_shrink4_256_stages_vs_oracle():
     assert ref["n_loc"] == 4435665 == M.n_loc and ref["alive"].shape == (108, 256)
     assert_same_detections(res, ref)
     assert M.n_weak == ref["n_weak"]
+
+
+def _random_deep_tree(rng, shape, max_depth, p_leaf=0.25):
+    """Random binary tree in pre-order (parent index < child index, like sklearn's), depth <= max_depth."""
+    m, n, C = shape
+    feat, thr, left, right, pred = [], [], [], [], []
+
+    def grow(d):
+        i = len(feat)
+        feat.append((int(rng.integers(0, m)), int(rng.integers(0, n)), int(rng.integers(0, C))))
+        thr.append(float(rng.uniform(2.0, 60.0)))
+        pred.append(float(rng.uniform(0.2, 1.0) * rng.choice([-1.0, 1.0])))
+        left.append(-1)
+        right.append(-1)
+        if d < max_depth and (d == 0 or rng.random() > p_leaf):
+            left[i] = grow(d + 1)
+            right[i] = grow(d + 1)
+        else:
+            feat[i] = None
+        return i
+
+    grow(0)
+    return feat, thr, left, right, pred
+
+
+def test_deep_trees_use_the_generic_kernel():
+    rng = np.random.default_rng(77)
+    shape = (12, 12, 4)
+    M = wb.Model(shape, dict(wb.default_channel_opts))
+    for t in range(18):
+        f, th, l, r, p = _random_deep_tree(rng, shape, 4 + t % 3)
+        M.append(wb.DTree(f, th, l, r, p), float("-inf") if t % 4 == 3 else float(np.float32(-0.4 * (t + 1))))
+    assert max(w.depth() for w in M.classifier) >= 5 and M.device_cascade().depth >= 5
+    img = synth_image(230, 310, 123)
+    res = M.detect_raw(img)
+    ref = oracle_detect(M, img)
+    assert ref["scores"].size > 0
+    assert_same_detections(res, ref)
+    assert M.n_loc == ref["n_loc"] and M.n_weak == ref["n_weak"]
+    # and on a caller-supplied channel image
+    X = np.random.default_rng(3).uniform(0, 60, (40, 100, 4)).astype(np.float32)
+    shape_, _, trees, thetas = oracle_model(M)
+    rs, cs, hs, alive = M.predict_on_image_stats(X)
+    ors, ocs, ohs, oalive = orc.cascade_predict_on_image(shape_, trees, thetas, X)
+    assert np.array_equal(rs, ors) and np.array_equal(cs, ocs) and np.array_equal(bits(hs), bits(ohs)) and np.array_equal(alive, oalive)

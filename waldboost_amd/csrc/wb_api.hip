@@ -97,16 +97,16 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         if (d > D) D = d;
         trees[s] = t;
     }
-    if (D > WB_CASC_MAX_DEPTH) {
-        wb_set_error("wb_model_create: tree depth %d exceeds the deepest cascade kernel (%d)", D, WB_CASC_MAX_DEPTH);
-        return WB_ERR_UNSUPPORTED;
-    }
+    const bool generic = D > WB_CASC_MAX_DEPTH;    // deep trees: generic node-walk kernel (no canonical form)
+    const int Dreal = D;
+    if (generic) D = 1;                            // (geometry fields below are unused in generic mode)
 
     // ---- cascade tile geometry: the largest tile whose LDS footprint leaves two workgroups per CU
     WbModel *M = new WbModel();
     memset(M, 0, sizeof(*M));
     M->n_stages = n_stages;
-    M->depth = D;
+    M->depth = generic ? Dreal : D;
+    M->generic = generic ? 1 : 0;
     M->m = m;
     M->n = n;
     M->C = C;
@@ -133,6 +133,40 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         return WB_ERR_UNSUPPORTED;
     }
     M->stage_dwords = WB_STAGE_DWORDS(D);
+    if (generic) {
+        // one thread per window, 4 x 64 windows per workgroup, features gathered from HBM/L2
+        M->rpw = 1;
+        M->waves = 4;
+        M->tile_rows = 4;
+        M->lds_rows = M->lds_pitch = 0;
+        M->lds_bytes = 0;
+        const int n_nodes = node_off[n_stages];
+        std::vector<int32_t> feat((size_t)n_nodes), lft((size_t)n_nodes), rgt((size_t)n_nodes);
+        for (int i = 0; i < n_nodes; ++i) {
+            feat[i] = feature[i * 3] | (feature[i * 3 + 1] << 8) | (feature[i * 3 + 2] << 16);
+            lft[i] = left[i];
+            rgt[i] = right[i];
+        }
+        hipError_t e = hipSuccess;
+        auto up = [&](void **dst, const void *src, size_t bytes) {
+            if (e == hipSuccess) e = hipMalloc(dst, bytes ? bytes : 4);
+            if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        };
+        up((void **)&M->g_node_off, node_off, (size_t)(n_stages + 1) * 4);
+        up((void **)&M->g_feat, feat.data(), (size_t)n_nodes * 4);
+        up((void **)&M->g_thr, threshold, (size_t)n_nodes * 4);
+        up((void **)&M->g_left, lft.data(), (size_t)n_nodes * 4);
+        up((void **)&M->g_right, rgt.data(), (size_t)n_nodes * 4);
+        up((void **)&M->g_pred, prediction, (size_t)n_nodes * 4);
+        up((void **)&M->g_theta, theta, (size_t)n_stages * 4);
+        if (e != hipSuccess) {
+            wb_set_error("wb_model_create: uploading the node arrays failed: %s", hipGetErrorString(e));
+            wb_model_destroy(M);
+            return WB_ERR_HIP;
+        }
+        *out = M;
+        return WB_OK;
+    }
 
     // ---- pack and upload the stage records
     const int NI = (1 << D) - 1, NL = 1 << D, SD = M->stage_dwords;
@@ -171,6 +205,9 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
 extern "C" int wb_model_destroy(WbModel *model) {
     if (!model) return WB_OK;
     if (model->stages_dev) (void)hipFree(model->stages_dev);
+    void *g[] = {model->g_node_off, model->g_feat, model->g_thr, model->g_left, model->g_right, model->g_pred, model->g_theta};
+    for (void *p : g)
+        if (p) (void)hipFree(p);
     delete model;
     return WB_OK;
 }

@@ -443,6 +443,88 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     }
 }
 
+// -------------------------------------------------------------------------------------------
+// Generic fallback for trees deeper than WB_CASC_MAX_DEPTH (or any shape): one thread per window,
+// 4 x 64 windows per workgroup, the reference's flat node arrays walked as training.py:84-96 does,
+// features gathered straight from HBM/L2.  Wave-synchronous in the stage index (dead lanes idle),
+// so the per-stage alive counts are ballots; survivors leave through an LDS list and one sharded
+// atomic per workgroup, like the tiled kernel.  Correctness fallback, not a tuned path.
+struct GenArgs {
+    const float *chn;
+    int64_t chn_stride;
+    const WbLevel *levels;
+    const WbTile *tiles;
+    int n_levels, n_tiles;
+    int T, m, n, C;
+    const int32_t *node_off, *feat, *left, *right;
+    const float *thr, *pred, *theta;
+    WbDet *det;
+    uint32_t *det_count;
+    uint32_t det_cap;
+    uint32_t *tile_hist;
+};
+
+__global__ __launch_bounds__(256) void cascade_generic_kernel(GenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    uint32_t *hist = reinterpret_cast<uint32_t *>(gsm);                       // T counters
+    uint2 *list = reinterpret_cast<uint2 *>(gsm + (((size_t)a.T * 4 + 15) & ~(size_t)15));   // 256 entries
+    __shared__ uint32_t n_list, base_slot;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const WbTile tile_d = a.tiles[blockIdx.x];
+    const WbLevel L = a.levels[tile_d.level];
+    const int b = blockIdx.y;
+    const int nr = L.u - a.m > 0 ? L.u - a.m : 0, nc = L.v - a.n > 0 ? L.v - a.n : 0;
+    const int r = tile_d.ty * 4 + wave, c = tile_d.tx * 64 + lane;
+    for (int t = tid; t < a.T; t += 256) hist[t] = 0;
+    if (tid == 0) n_list = 0;
+    __syncthreads();
+    const float *chn = a.chn + (int64_t)b * a.chn_stride + L.chn_off;
+    bool alive = r < nr && c < nc;
+    float h = 0.f;
+    for (int t = 0; t < a.T; ++t) {
+        int cnt = __popcll(__ballot(alive));
+        if (cnt == 0) break;
+        if (lane == 0) atomicAdd(&hist[t], (uint32_t)cnt);
+        if (alive) {
+            const int o = a.node_off[t], k = a.node_off[t + 1] - o;
+            int node = 0;
+            for (int step = 0; step < k; ++step) {                            // a walk visits a node at most once
+                int l = a.left[o + node];
+                if (l < 0) break;
+                int f = a.feat[o + node];
+                float v = chn[((int64_t)(r + (f & 255)) * L.v + (c + ((f >> 8) & 255))) * a.C + ((f >> 16) & 255)];
+                node = (v <= a.thr[o + node]) ? l : a.right[o + node];
+            }
+            h = h + a.pred[o + node];
+            const float th = a.theta[t];
+            alive = (th == -INFINITY) || (h >= th);
+        }
+    }
+    if (alive) {
+        uint32_t s = atomicAdd(&n_list, 1u);
+        list[s] = make_uint2((uint32_t)(wave * 64 + lane), __float_as_uint(h));
+    }
+    __syncthreads();
+    const uint32_t shard = blockIdx.x % WB_DET_SHARDS;
+    if (tid == 0) base_slot = n_list ? atomicAdd(a.det_count + shard, n_list) : 0u;
+    uint32_t *th_row = a.tile_hist + ((int64_t)b * a.n_tiles + blockIdx.x) * a.T;
+    for (int t = tid; t < a.T; t += 256) th_row[t] = hist[t];
+    __syncthreads();
+    if ((uint32_t)tid < n_list) {
+        uint2 e = list[tid];
+        uint32_t slot = base_slot + tid;
+        if (slot < a.det_cap) {
+            WbDet d;
+            d.image = b;
+            d.level = tile_d.level;
+            d.r = (uint16_t)(tile_d.ty * 4 + (int)(e.x >> 6));
+            d.c = (uint16_t)(tile_d.tx * 64 + (int)(e.x & 63));
+            d.score = __uint_as_float(e.y);
+            a.det[(size_t)shard * a.det_cap + slot] = d;
+        }
+    }
+}
+
 // alive[b][level][t] = sum over the level's tiles of tile_hist[b][tile][t]; grid (n_levels, batch),
 // 1024 threads = 16 groups x 64 stages: group g sums tiles lo+g, lo+g+16, ... (independent loads,
 // several in flight), then the 16 partial sums meet in LDS.
@@ -587,6 +669,23 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const float
     a.dbg = dbg;
     dim3 grid((unsigned)n_tiles, (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;
+    if (model->generic) {
+        GenArgs g;
+        g.chn = chn; g.chn_stride = chn_stride; g.levels = levels; g.tiles = tiles;
+        g.n_levels = n_levels; g.n_tiles = n_tiles;
+        g.T = model->n_stages; g.m = model->m; g.n = model->n; g.C = model->C;
+        g.node_off = model->g_node_off; g.feat = model->g_feat; g.left = model->g_left; g.right = model->g_right;
+        g.thr = model->g_thr; g.pred = model->g_pred; g.theta = model->g_theta;
+        g.det = det; g.det_count = det_count; g.det_cap = shard_capacity; g.tile_hist = tile_hist;
+        size_t lds = (((size_t)g.T * 4 + 15) & ~(size_t)15) + 256 * 8;
+        WB_REQUIRE(lds <= 64 * 1024, "wb_cascade_launch: %d stages exceed the generic kernel's LDS", g.T);
+        hipLaunchKernelGGL(cascade_generic_kernel, grid, dim3(256), lds, st, g);
+        if (g.T > 0)
+            hipLaunchKernelGGL(alive_reduce_kernel, dim3(n_levels, grid.y), dim3(1024), 0, st, tile_hist, tile_csr,
+                               n_levels, n_tiles, g.T, alive);
+        WB_HIP_CHECK(hipGetLastError());
+        return WB_OK;
+    }
     switch (model->depth) {
         case 1: return launch_depth<1>(st, grid, a, model->rpw, model->waves, (size_t)model->lds_bytes);
         case 2: return launch_depth<2>(st, grid, a, model->rpw, model->waves, (size_t)model->lds_bytes);

@@ -68,5 +68,13 @@ struct WbModel {
     int lds_bytes;
     int lds_stages;   // stage records mirrored in LDS (n_stages if the table is <= 16 KiB, else 0)
     int stage_dwords;
-    int32_t *stages_dev;        // (n_stages + G) stage records with LDS float offsets
+    int32_t *stages_dev;        // (n_stages + G) stage records with LDS byte offsets
+    // trees deeper than WB_CASC_MAX_DEPTH: generic node-walk kernel on the reference's own flat arrays
+    int generic;                // 1 = use cascade_generic_kernel
+    int32_t *g_node_off;        // [n_stages + 1]
+    int32_t *g_feat;            // [n_nodes] row | col << 8 | channel << 16
+    float *g_thr;               // [n_nodes]
+    int32_t *g_left, *g_right;  // [n_nodes] child index inside the stage's tree, -1 on leaves
+    float *g_pred;              // [n_nodes]
+    float *g_theta;             // [n_stages]
 };
