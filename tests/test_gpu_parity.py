@@ -401,3 +401,27 @@ def test_deep_trees_use_the_generic_kernel():
     rs, cs, hs, alive = M.predict_on_image_stats(X)
     ors, ocs, ohs, oalive = orc.cascade_predict_on_image(shape_, trees, thetas, X)
     assert np.array_equal(rs, ors) and np.array_equal(cs, ocs) and np.array_equal(bits(hs), bits(ohs)) and np.array_equal(alive, oalive)
+
+
+@pytest.mark.parametrize("shape,C", [((12, 12, 3), 3), ((9, 20, 1), 1), ((6, 6, 7), 7)])
+def test_predict_on_image_other_channel_counts(shape, C):
+    rng = np.random.default_rng(31 + C)
+    X = rng.uniform(0, 60, (50, 120, C)).astype(np.float32)
+    M = random_model(60 + C, 25, 2, shape=shape)
+    sh, _, trees, thetas = oracle_model(M)
+    rs, cs, hs, alive = M.predict_on_image_stats(X)
+    ors, ocs, ohs, oalive = orc.cascade_predict_on_image(sh, trees, thetas, X)
+    assert ors.size > 0
+    assert np.array_equal(rs, ors) and np.array_equal(cs, ocs) and np.array_equal(bits(hs), bits(ohs)) and np.array_equal(alive, oalive)
+
+
+def test_window_too_large_for_an_lds_tile_falls_back_to_the_generic_kernel():
+    rng = np.random.default_rng(5)
+    X = rng.uniform(0, 60, (150, 260, 4)).astype(np.float32)
+    M = random_model(71, 12, 2, shape=(100, 120, 4))
+    assert M.device_cascade().tile_rows == 4            # generic kernel geometry
+    sh, _, trees, thetas = oracle_model(M)
+    rs, cs, hs, alive = M.predict_on_image_stats(X)
+    ors, ocs, ohs, oalive = orc.cascade_predict_on_image(sh, trees, thetas, X)
+    assert ors.size > 0
+    assert np.array_equal(rs, ors) and np.array_equal(cs, ocs) and np.array_equal(bits(hs), bits(ohs)) and np.array_equal(alive, oalive)

@@ -97,7 +97,9 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         if (d > D) D = d;
         trees[s] = t;
     }
-    const bool generic = D > WB_CASC_MAX_DEPTH;    // deep trees: generic node-walk kernel (no canonical form)
+    // deep trees, or windows whose LDS tile would not fit a CU: generic node-walk kernel
+    const int min_lds = C * (4 + m - 1) * (WB_CASC_TC + n) * 4 + 4 * WB_CASC_TC * 8 + n_stages * 4;
+    const bool generic = D > WB_CASC_MAX_DEPTH || min_lds > 150 * 1024 || getenv("WB_CASC_GENERIC") != nullptr;
     const int Dreal = D;
     if (generic) D = 1;                            // (geometry fields below are unused in generic mode)
 
@@ -126,7 +128,7 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
                        M->lds_stages * WB_STAGE_DWORDS(D) * 4;
         if (M->lds_bytes <= budget || rpw <= 1) break;
     }
-    if (M->lds_bytes > 160 * 1024) {
+    if (!generic && M->lds_bytes > 160 * 1024) {
         wb_set_error("wb_model_create: window (%d,%d,%d) with %d stages needs %d B of LDS (> 160 KiB)", m, n, C,
                      n_stages, M->lds_bytes);
         delete M;
