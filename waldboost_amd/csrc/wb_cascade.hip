@@ -31,6 +31,8 @@
 // bit-identical to the reference's `hs += ...; mask = hs >= theta`.
 #include <stdlib.h>
 
+#include <vector>
+
 #include "wb_common.h"
 
 namespace {
@@ -56,6 +58,22 @@ struct CascArgs {
 };
 
 __device__ inline float as_f(int32_t x) { return __int_as_float(x); }
+
+// Diagnostic build only (make STAMPS=1): wave 0 of every workgroup stores s_memrealtime at its phase
+// boundaries into a private slot (plain stores, nothing reads them in the kernel); the host turns
+// them into mean wall-clock per phase (wb_debug_cascade_stamps).  Never part of a measured build.
+#ifdef WB_CASC_STAMPS
+#define WB_STAMP_SLOTS 8
+#define WB_STAMP_WGS (1 << 16)
+__device__ unsigned long long g_stamps[WB_STAMP_WGS * WB_STAMP_SLOTS];
+#define WB_STAMP(k)                                                                                       \
+    do {                                                                                                  \
+        unsigned long long _wg = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;                 \
+        if (threadIdx.x == 0 && _wg < WB_STAMP_WGS) g_stamps[_wg * WB_STAMP_SLOTS + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define WB_STAMP(k) do {} while (0)
+#endif
 
 
 // a[path] for the root-to-node path bits[0..] (false = left, true = right), first decision first
@@ -156,6 +174,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
 
     // LDS mirror of the stage table (when it is small enough): the tail reads one record per lane
     int4 *stab = reinterpret_cast<int4 *>(smem + (((size_t)tile_floats * 4 + (size_t)TR * 64 * 8 + (size_t)T * 4 + 15) & ~(size_t)15));
+    WB_STAMP(0);
     for (int t = tid; t < T; t += NT) hist[t] = 0;
     for (int i = tid; i < a.lds_stages * (SD / 4); i += NT) stab[i] = reinterpret_cast<const int4 *>(stages)[i];
 
@@ -212,6 +231,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         }
     }
     __syncthreads();
+    WB_STAMP(1);
     if (a.dbg & 2) return;
 
     // ---- phase A: RPW windows per lane through stages [0, S0)
@@ -265,6 +285,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         n_q += cnt;
     }
 
+    WB_STAMP(2);
     if (a.dbg & 4) return;
     // ---- phase B: dense re-packed survivors, stage segments [S0,2S0), [2S0,4S0), ...
     int t_begin = tA;
@@ -347,9 +368,11 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         run_segments(8);
         if (a.dbg & 8) return;
         repack(8);
+        WB_STAMP(3);
     }
     // (a second re-pack at stage 16 was measured slower: 1.83 vs 1.73 ms per 32 images)
     run_segments(T);
+    WB_STAMP(4);
     if (a.dbg & 16) return;
 
     // ---- stage-parallel tail: one window at a time, lane i evaluates stage rs+i
@@ -407,6 +430,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         n_q = n_out;
     }
 
+    WB_STAMP(5);
     if (a.dbg & 32) return;
     // ---- epilogue: the wave queues now hold the windows alive after stage T-1.  One atomic per
     //      workgroup reserves their slots in one of the sharded output buffers.
@@ -424,6 +448,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     uint32_t *th = a.tile_hist + ((int64_t)b * a.n_tiles + blockIdx.x) * a.T;
     for (int t = tid; t < T; t += NT) th[t] = hist[t];
     __syncthreads();
+    WB_STAMP(6);
     if (n_q > 0) {
         uint32_t o = wg_base;
         for (int w = 0; w < wave; ++w) o += wcnt[w];
@@ -441,6 +466,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
             }
         }
     }
+    WB_STAMP(7);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -723,3 +749,23 @@ extern "C" int wb_boxes_launch(void *stream, const WbDet *det, int64_t n_det, co
     return WB_OK;
 }
 
+
+#ifdef WB_CASC_STAMPS
+// Diagnostic build: mean microseconds between consecutive stamps over the first n_wg workgroups
+// of the last cascade launch (s_memrealtime ticks at 100 MHz).
+extern "C" int wb_debug_cascade_stamps(int n_wg, double *mean_us7, double *lifetime_us) {
+    if (n_wg > WB_STAMP_WGS) n_wg = WB_STAMP_WGS;
+    std::vector<unsigned long long> h((size_t)n_wg * WB_STAMP_SLOTS);
+    WB_HIP_CHECK(hipDeviceSynchronize());
+    WB_HIP_CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stamps), h.size() * 8));
+    double acc[7] = {0}, life = 0;
+    for (int w = 0; w < n_wg; ++w) {
+        const unsigned long long *s = &h[(size_t)w * WB_STAMP_SLOTS];
+        for (int k = 0; k < 7; ++k) acc[k] += (double)(s[k + 1] - s[k]);
+        life += (double)(s[7] - s[0]);
+    }
+    for (int k = 0; k < 7; ++k) mean_us7[k] = acc[k] / n_wg / 100.0;
+    *lifetime_us = life / n_wg / 100.0;
+    return WB_OK;
+}
+#endif
