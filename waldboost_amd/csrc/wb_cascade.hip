@@ -236,13 +236,13 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
 
     // ---- phase A: RPW windows per lane through stages [0, S0)
     float hs[RPW];
-    bool live[RPW];
-    int base[RPW];
+    unsigned long long lm[RPW];          // liveness of the 64 windows of row j as a lane mask: the bookkeeping
+    int base[RPW];                       // (counts, rejection) is then scalar work, not per-lane VALU
     const int wr = wave * RPW;
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         hs[j] = 0.f;
-        live[j] = (c0 + lane < nc) && (r0 + wr + j < nr);
+        lm[j] = __ballot((c0 + lane < nc) && (r0 + wr + j < nr));
         base[j] = ((wr + j) * pitch + lane) * 4;
     }
     const int tA = T < S0 ? T : S0;
@@ -261,32 +261,31 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
             if (t + g >= tA) break;
             int cnt = 0;
 #pragma unroll
-            for (int j = 0; j < RPW; ++j) cnt += __popcll(__ballot(live[j]));
+            for (int j = 0; j < RPW; ++j) cnt += __popcll(lm[j]);
             if (cnt && lane == 0) atomicAdd(&hist[t + g], (uint32_t)cnt);
             const bool rejects = st[g].theta != -INFINITY;
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
-                float h = hs[j] + p[g][j];
-                hs[j] = h;                                   // (a dead window's sum is never read again)
-                live[j] = live[j] && (!rejects || h >= st[g].theta);
+                hs[j] = hs[j] + p[g][j];                      // (a dead window's sum is never read again)
+                if (rejects) lm[j] &= __ballot(hs[j] >= st[g].theta);
             }
         }
     }
+    if (a.dbg & 4) return;
 
     // survivors of phase A -> this wave's queue
     int n_q = 0;
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
-        unsigned long long mask = __ballot(live[j]);
+        const unsigned long long mask = lm[j];
         int cnt = __popcll(mask);
         if (cnt == 0) continue;
         int rank = lane_rank(mask);
-        if (live[j]) queue[n_q + rank] = make_uint2((uint32_t)((wr + j) * 64 + lane), __float_as_uint(hs[j]));
+        if ((mask >> lane) & 1ull) queue[n_q + rank] = make_uint2((uint32_t)((wr + j) * 64 + lane), __float_as_uint(hs[j]));
         n_q += cnt;
     }
-
     WB_STAMP(2);
-    if (a.dbg & 4) return;
+
     // ---- phase B: dense re-packed survivors, stage segments [S0,2S0), [2S0,4S0), ...
     int t_begin = tA;
     // wave-synchronous segments from t_begin up to (at most) t_stop, compacting after each
@@ -298,13 +297,14 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
             int n_out = 0;
             for (int qb = 0; qb < n_q; qb += 64) {
                 int i = qb + lane;
-                bool alive = i < n_q;
-                uint2 e = alive ? queue[i] : make_uint2(0u, 0u);
+                const bool mine = i < n_q;
+                unsigned long long am = __ballot(mine);                    // alive lanes of this chunk, as a mask
+                uint2 e = mine ? queue[i] : make_uint2(0u, 0u);
                 int pos = (int)e.x;
                 float h = __uint_as_float(e.y);
                 int wbase = ((pos >> 6) * pitch + (pos & 63)) * 4;
                 for (int t = t_begin; t < t_end; t += G) {
-                    if (__ballot(alive) == 0ull) break;
+                    if (am == 0ull) break;
                     Stage<D> st[G];
                     const int32_t *sp = stages + (size_t)__builtin_amdgcn_readfirstlane(t) * SD;
 #pragma unroll
@@ -315,17 +315,16 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         if (t + g >= t_end) break;
-                        int cnt = __popcll(__ballot(alive));
+                        int cnt = __popcll(am);
                         if (cnt && lane == 0) atomicAdd(&hist[t + g], (uint32_t)cnt);
                         h = h + p[g];                        // (a dead window's sum is never read again)
-                        alive = alive && (st[g].theta == -INFINITY || h >= st[g].theta);
+                        if (st[g].theta != -INFINITY) am &= __ballot(h >= st[g].theta);
                     }
                 }
-                unsigned long long mask = __ballot(alive);
-                int cnt = __popcll(mask);
+                int cnt = __popcll(am);
                 if (cnt) {
                     // in place: n_out + rank <= qb + lane, and this wave already holds chunk qb in registers
-                    if (alive) queue[n_out + lane_rank(mask)] = make_uint2((uint32_t)pos, __float_as_uint(h));
+                    if ((am >> lane) & 1ull) queue[n_out + lane_rank(am)] = make_uint2((uint32_t)pos, __float_as_uint(h));
                     n_out += cnt;
                 }
             }

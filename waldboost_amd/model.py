@@ -72,8 +72,12 @@ class Model:
         self._device = None
 
     def device_cascade(self):
-        """The device-side cascade for the current stage list (rebuilt after ``append``)."""
-        sig = (len(self.classifier), tuple(self.shape))
+        """The device-side cascade for the current stage list.  `classifier` and `theta` are plain
+        public lists in the reference and callers edit them in place, so the cached handle is
+        keyed by their current content, not only by `append` calls."""
+        sig = (tuple(self.shape), tuple(id(w) for w in self.classifier),
+               np.array([_engine.theta_as_f32(t) for t in self.theta], np.float32).tobytes(),
+               tuple(w.threshold.tobytes() + w.prediction.tobytes() for w in self.classifier))
         if self._device is None or self._device[0] != sig:
             self._device = (sig, _engine.DeviceCascade(self.shape, self.classifier, self.theta))
         return self._device[1]
