@@ -273,18 +273,52 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     }
     if (a.dbg & 4) return;
 
-    // survivors of phase A -> this wave's queue
-    int n_q = 0;
+    // ---- survivors of phase A.  If more stages follow, the survivors of the whole workgroup are
+    //      pooled: by stage 8 a wave keeps only a fraction of its windows (half-empty chunks in
+    //      every wave); pooled, they fill whole chunks of 64 for a few waves and the others are
+    //      done.  (A second pooling at stage 16 was measured slower.)
+    int my_cnt = 0;
 #pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const unsigned long long mask = lm[j];
-        int cnt = __popcll(mask);
-        if (cnt == 0) continue;
-        int rank = lane_rank(mask);
-        if ((mask >> lane) & 1ull) queue[n_q + rank] = make_uint2((uint32_t)((wr + j) * 64 + lane), __float_as_uint(hs[j]));
-        n_q += cnt;
+    for (int j = 0; j < RPW; ++j) my_cnt += __popcll(lm[j]);
+    uint32_t total = (uint32_t)my_cnt, before = 0;
+    bool pooled = false;
+    uint2 *wgq = reinterpret_cast<uint2 *>(smem + (size_t)tile_floats * 4);
+    if (T > S0) {
+        if (lane == 0) wcnt[wave] = (uint32_t)my_cnt;
+        __syncthreads();
+        total = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            uint32_t c = wcnt[w];
+            if (w < wave) before += c;
+            total += c;
+        }
+        pooled = total <= 64u * WAVES;                            // same decision in every wave
+    }
+    {
+        uint2 *dstq = pooled ? wgq + before : queue;
+        int n_loc = 0;
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const unsigned long long mask = lm[j];
+            int cnt = __popcll(mask);
+            if (cnt == 0) continue;
+            if ((mask >> lane) & 1ull)
+                dstq[n_loc + lane_rank(mask)] = make_uint2((uint32_t)((wr + j) * 64 + lane), __float_as_uint(hs[j]));
+            n_loc += cnt;
+        }
+    }
+    int n_q = my_cnt;
+    if (T > S0) {
+        __syncthreads();                                          // pooled entries visible; wcnt free again
+        if (pooled) {
+            queue = wgq + 64 * wave;
+            int left = (int)total - 64 * wave;
+            n_q = left < 0 ? 0 : (left > 64 ? 64 : left);
+        }
     }
     WB_STAMP(2);
+    WB_STAMP(3);
 
     // ---- phase B: dense re-packed survivors, stage segments [S0,2S0), [2S0,4S0), ...
     int t_begin = tA;
@@ -333,43 +367,8 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         }
     };
 
-    // ---- workgroup-wide re-pack at stage 8: by then a wave keeps only a fraction of its
-    //      windows (half-empty chunks in every wave); pooled, the tile's survivors fill whole
-    //      chunks of 64 for a few waves and the others are done.
-    auto repack = [&](int t_at) {
-        uint2 ent[RPW];
-#pragma unroll
-        for (int k = 0; k < RPW; ++k) ent[k] = (k * 64 + lane < n_q) ? queue[k * 64 + lane] : make_uint2(0u, 0u);
-        if (lane == 0) wcnt[wave] = (uint32_t)n_q;
-        __syncthreads();
-        uint32_t total = 0, before = 0;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            uint32_t c = wcnt[w];
-            if (w < wave) before += c;
-            total += c;
-        }
-        const bool merge = total <= 64u * WAVES;                  // same decision in every wave
-        __syncthreads();                                          // everyone has read wcnt and its own entries
-        if (merge) {
-            uint2 *wgq = reinterpret_cast<uint2 *>(smem + (size_t)tile_floats * 4);
-#pragma unroll
-            for (int k = 0; k < RPW; ++k)
-                if (k * 64 + lane < n_q) wgq[before + k * 64 + lane] = ent[k];
-            __syncthreads();
-            queue = wgq + 64 * wave;
-            int left = (int)total - 64 * wave;
-            n_q = left < 0 ? 0 : (left > 64 ? 64 : left);
-        }
-        t_begin = t_at;              // (a wave that ran dry earlier may have been handed windows)
-    };
-    if (T > 8) {
-        run_segments(8);
-        if (a.dbg & 8) return;
-        repack(8);
-        WB_STAMP(3);
-    }
-    // (a second re-pack at stage 16 was measured slower: 1.83 vs 1.73 ms per 32 images)
+    static_assert(S0 == 8, "the pooling above assumes phase A ends at stage 8");
+    if (a.dbg & 8) return;
     run_segments(T);
     WB_STAMP(4);
     if (a.dbg & 16) return;
