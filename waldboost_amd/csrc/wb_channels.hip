@@ -326,11 +326,32 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
             y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
             x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
             const Tap tr = rtap[y], tc = ctap[x];
-            const T *r0 = src + (int64_t)tr.i0 * L.src_w;
-            const T *r1 = src + (int64_t)tr.i1 * L.src_w;
-            const T a00 = r0[tc.i0], a01 = r0[tc.i1], a10 = r1[tc.i0], a11 = r1[tc.i1];
-            R[k * RW + q] = ident ? (float)a00
-                                  : Src<T>::finish(resample_f64((double)a00, (double)a01, (double)a10, (double)a11, tr, tc), mn, mx);
+            T a00, a01, a10, a11;
+            bool from_lds = false;
+            if constexpr (sizeof(T) == 1) {
+                if (staged) {                        // the staged patch covers these columns too
+                    const unsigned char *patch = uni;
+                    const uintptr_t base = reinterpret_cast<uintptr_t>(src);
+                    const int o0 = (tr.i0 - r_lo) * PPITCH + (int)((base + (uintptr_t)((int64_t)tr.i0 * L.src_w + c_lo)) & 3);
+                    const int o1 = (tr.i1 - r_lo) * PPITCH + (int)((base + (uintptr_t)((int64_t)tr.i1 * L.src_w + c_lo)) & 3);
+                    a00 = patch[o0 + tc.i0 - c_lo]; a01 = patch[o0 + tc.i1 - c_lo];
+                    a10 = patch[o1 + tc.i0 - c_lo]; a11 = patch[o1 + tc.i1 - c_lo];
+                    from_lds = true;
+                }
+            }
+            if (!from_lds) {
+                const T *r0 = src + (int64_t)tr.i0 * L.src_w;
+                const T *r1 = src + (int64_t)tr.i1 * L.src_w;
+                a00 = r0[tc.i0]; a01 = r0[tc.i1]; a10 = r1[tc.i0]; a11 = r1[tc.i1];
+            }
+            float out = 0.0f;
+            bool ok = ident;
+            if (ident) out = (float)a00;
+            if constexpr (Src<T>::kFastResample)
+                if (!ok) ok = Src<T>::fast((float)a00, (float)a01, (float)a10, (float)a11, (float)tr.w0, (float)tr.w1,
+                                           (float)tc.w0, (float)tc.w1, mnf, mxf, out);
+            if (!ok) out = Src<T>::finish(resample_f64((double)a00, (double)a01, (double)a10, (double)a11, tr, tc), mn, mx);
+            R[k * RW + q] = out;
         }
     }
     __syncthreads();
