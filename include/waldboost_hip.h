@@ -15,6 +15,9 @@
  *   reference waldboost/channels.py:111-146 (channel_pyramid: resize :132,
  *        grad_hist :40-52, gradients :16-21, avg_pool_2 :55-64, smooth :78-90)
  *        -> wb_channels_launch
+ *   reference waldboost/fpga/channels.py:5-67 (grad_hist_4_u1, grad_mag_u1) and
+ *        waldboost/channels.py:30-37 (grad_mag) as channel_opts["channels"]
+ *        -> wb_channels_launch with channel_func = WB_CHN_*
  *   reference waldboost/model.py:62-67,272-283 (Model ctor/append) +
  *        waldboost/training.py:24-31 (DTree.__init__)
  *        -> wb_model_create / wb_model_destroy / wb_model_info
@@ -35,7 +38,7 @@
 extern "C" {
 #endif
 
-#define WB_ABI_VERSION 1
+#define WB_ABI_VERSION 2
 
 #define WB_OK 0
 #define WB_ERR_INVALID (-1)     /* bad argument / malformed model */
@@ -45,9 +48,21 @@ extern "C" {
 #define WB_DTYPE_U8 0
 #define WB_DTYPE_F32 1
 
-/* Channel images are [u][v][C] float32 everywhere (the layout channel_pyramid hands to callers):
- * with C = 4 a pixel is one aligned float4, so the channel kernel stores 16 B per lane and a
- * cascade tile row is one contiguous run in HBM. */
+/* Channel functions (channel_opts["channels"] of the reference) the channel kernel implements:
+ *   WB_CHN_GRAD_HIST       waldboost.channels.grad_hist (n_bins=4)    4 x float32  channels.py:40-52
+ *   WB_CHN_GRAD_HIST_4_U1  waldboost.fpga.grad_hist_4_u1              4 x uint8    fpga/channels.py:29-53
+ *   WB_CHN_GRAD_MAG_U1     waldboost.fpga.grad_mag_u1                 1 x uint8    fpga/channels.py:56-67
+ *   WB_CHN_GRAD_MAG        waldboost.channels.grad_mag (norm=5,eps=1e-3) 1 x float32 channels.py:30-37 */
+#define WB_CHN_GRAD_HIST 0
+#define WB_CHN_GRAD_HIST_4_U1 1
+#define WB_CHN_GRAD_MAG_U1 2
+#define WB_CHN_GRAD_MAG 3
+
+/* Channel images are [u][v][C] everywhere (the layout channel_pyramid hands to callers), in the
+ * dtype the channel function produces (float32 or uint8): with C = 4 a pixel is one aligned
+ * float4 (or one dword), so the channel kernel stores one vector per lane and a cascade tile row
+ * is one contiguous run in HBM.  Offsets and strides of channel buffers (WbLevel.chn_off,
+ * chn_stride) count ELEMENTS of that dtype; every level starts on a multiple of 4 elements. */
 
 #define WB_MAX_OCTAVES 24
 
@@ -119,6 +134,9 @@ const char *wb_last_error(void);
 /* Tile sizes of the channel kernel for a given shrink (outputs per workgroup). */
 int wb_channels_tile(int shrink, int *tile_u, int *tile_v);
 
+/* Channel count and element dtype (WB_DTYPE_*) a channel function produces. */
+int wb_channel_func_info(int channel_func, int *n_channels, int *chn_dtype);
+
 /* Octave pyramid of the raw image + per-octave min/max (the clip range of the resize).
  *   img      dev  [batch][H][W] of dtype, image b at img + b*img_stride elements
  *   oct      dev  per-image octave buffer for octaves 1..n_oct-1 (octave k at
@@ -131,20 +149,22 @@ int wb_octaves_launch(void *stream, const void *img, int dtype, int batch, int H
                       int64_t img_stride, void *oct, int64_t oct_stride, const int64_t *oct_off,
                       int n_oct, uint32_t *minmax);
 
-/* All levels of all images: bilinear resize (fp64) -> Sobel gradients -> 4 oriented
- * channels (fp64 projection) -> shrink -> 3x3 smooth, fused per tile.
+/* All levels of all images: bilinear resize (fp64) -> channel function (grad_hist: Sobel
+ * gradients -> 4 oriented channels with fp64 projection) -> shrink -> 3x3 smooth, fused per tile.
+ *   channel_func  WB_CHN_*; the uint8 functions take uint8 images only (WB_ERR_UNSUPPORTED otherwise)
  *   levels   dev  WbLevel[n_levels];  tiles dev WbTile[n_tiles] (tile = wb_channels_tile)
  *   taps     dev  WbTap table addressed by WbLevel.tap_off
  *   img/oct  as for wb_octaves_launch; both buffers must extend 16 bytes past their last element
  *            (source rows are fetched with 4-byte-aligned dword loads)
- *   cs_sn    HOST double[8]: cos(theta_k), k=0..3 then sin(theta_k) (channels.py:43-46)
- *   chn      dev  float [u][v][4] per level, image b at chn + b*chn_stride, level l at
- *                 + levels[l].chn_off (16-byte aligned) */
+ *   cs_sn    HOST double[8]: cos(theta_k), k=0..3 then sin(theta_k) (channels.py:43-46); used by
+ *            WB_CHN_GRAD_HIST only
+ *   chn      dev  [u][v][C] per level in the channel function's dtype, image b at
+ *                 chn + b*chn_stride, level l at + levels[l].chn_off (elements) */
 int wb_channels_launch(void *stream, const void *img, int64_t img_stride, const void *oct,
                        int64_t oct_stride, int dtype, int batch, const WbLevel *levels, int n_levels,
                        const WbTile *tiles, int n_tiles, const uint32_t *minmax, int n_oct,
-                       const WbTap *taps, int shrink, int smooth, const double *cs_sn, float *chn,
-                       int64_t chn_stride);
+                       const WbTap *taps, int channel_func, int shrink, int smooth, const double *cs_sn,
+                       void *chn, int64_t chn_stride);
 
 /* Build the device-side cascade from the reference's tree arrays (all HOST pointers).
  *   node_off  int32[n_stages+1]  first node of each stage's tree in the flat arrays
@@ -162,7 +182,9 @@ int wb_model_destroy(WbModel *model);
 int wb_model_info(const WbModel *model, WbModelInfo *info);
 
 /* Dense sliding-window cascade over all levels of all images.
- *   chn           [u][v][C] per level as written by wb_channels_launch (or caller-provided)
+ *   chn           [u][v][C] per level as written by wb_channels_launch (or caller-provided), of
+ *                 chn_dtype WB_DTYPE_F32 or WB_DTYPE_U8 (uint8 values compare against the float32
+ *                 thresholds as their exact float32 values, like NumPy's uint8 <= float32)
  *   tiles         dev WbTile[n_tiles]: tiles of tile_rows x tile_cols WINDOWS over the
  *                 (u-m) x (v-n) window grid of each level
  *   det           dev WbDet[WB_DET_SHARDS][shard_capacity]; det_count dev uint32[WB_DET_SHARDS]:
@@ -176,16 +198,16 @@ int wb_model_info(const WbModel *model, WbModelInfo *info);
  *                 over the level's tiles by a small follow-up kernel; overwritten
  * det_count is ACCUMULATED into: the caller zeroes it.  Record order is unspecified; sort by
  * (image, level, r, c) to obtain the reference order. */
-int wb_cascade_launch(void *stream, const WbModel *model, const float *chn, int64_t chn_stride,
-                      int batch, const WbLevel *levels, int n_levels,
+int wb_cascade_launch(void *stream, const WbModel *model, const void *chn, int chn_dtype,
+                      int64_t chn_stride, int batch, const WbLevel *levels, int n_levels,
                       const WbTile *tiles, const int32_t *tile_csr, int n_tiles, WbDet *det,
                       uint32_t *det_count, uint32_t shard_capacity, uint32_t *tile_hist,
                       uint32_t *alive);
 
 /* One tree evaluated at explicit window origins (rs[i], cs[i]) of an HWC channel image
- * X[u][v][C]; out[i] = prediction of the leaf reached (training.py:84-96). Tree arrays
- * and rs/cs/out are dev pointers. */
-int wb_tree_eval_launch(void *stream, const float *X, int u, int v, int C, const int32_t *rs,
+ * X[u][v][C] of x_dtype (WB_DTYPE_F32 / WB_DTYPE_U8); out[i] = prediction of the leaf reached
+ * (training.py:84-96). Tree arrays and rs/cs/out are dev pointers. */
+int wb_tree_eval_launch(void *stream, const void *X, int x_dtype, int u, int v, int C, const int32_t *rs,
                         const int32_t *cs, int64_t n_pos, const uint8_t *feature,
                         const float *threshold, const int8_t *left, const int8_t *right,
                         const float *prediction, int n_nodes, float *out);

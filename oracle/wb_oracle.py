@@ -17,6 +17,8 @@ computes under NumPy 2.x / SciPy 1.15 for
   * ``skimage.transform.resize(order=1, anti_aliasing=False, preserve_range=True)``
     as called at channels.py:132 (third party, absent here: restated as
     scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True) + clip)
+  * ``waldboost.channels.grad_mag``             (reference channels.py:11-37)
+  * ``waldboost.fpga.grad_hist_4_u1 / grad_mag_u1`` (reference fpga/channels.py:5-67)
   * ``waldboost.model.Model.predict_on_image``  (reference model.py:216-259)
   * ``waldboost.training.DTree.predict_on_image`` (reference training.py:84-96)
   * ``waldboost.model.Model.get_boxes/detect``  (reference model.py:136-179)
@@ -38,7 +40,8 @@ import numpy as np
 
 __all__ = [
     "level_plan", "octave_shapes", "image_octaves", "resize_bilinear", "gradients",
-    "grad_hist", "avg_pool_2", "smooth_image_3d", "channel_pyramid",
+    "grad_hist", "grad_mag", "grad_hist_4_u1", "grad_mag_u1", "triangle_kernel", "CHANNEL_FUNCS",
+    "avg_pool_2", "smooth_image_3d", "channel_pyramid",
     "tree_predict_on_image", "cascade_predict_on_image", "get_boxes", "detect",
 ]
 
@@ -214,6 +217,83 @@ def grad_hist(image, n_bins=4, full=False, bias=0):
     return np.sign(chns) * value if full else value
 
 
+# --------------------------------------------------------------------------- f2: other channel functions
+def triangle_kernel(n):
+    """reference channels.py:11-13."""
+    H = (np.r_[:n + 1, n - 1:-1:-1] + 1).astype("f")
+    return H / H.sum()
+
+
+def _conv_sym(a32, w32, axis):
+    """scipy.ndimage.convolve1d(a, w, axis) for an odd symmetric kernel, mode='reflect':
+    NI_Correlate1D's symmetric branch -- fp64, tmp = x[l]*w[c]; then for jj = -size1..-1:
+    tmp += (x[l+jj] + x[l-jj]) * w[c+jj] -- and one rounding to the array dtype on the store."""
+    w = np.asarray(w32, np.float64)
+    size1 = w.size // 2
+    a = np.moveaxis(a32.astype(np.float64), axis, 0)
+    n = a.shape[0]
+    idx = np.arange(-size1, n + size1)
+    # 'reflect': (d c b a | a b c d | d c b a), valid for any pad length
+    period = 2 * n
+    idx = np.mod(idx, period)
+    idx = np.where(idx >= n, period - 1 - idx, idx)
+    p = a[idx]
+    tmp = p[size1:size1 + n] * w[size1]
+    for jj in range(-size1, 0):
+        tmp = tmp + (p[size1 + jj:size1 + jj + n] + p[size1 - jj:size1 - jj + n]) * w[size1 + jj]
+    return np.moveaxis(tmp, 0, axis).astype(a32.dtype)
+
+
+def grad_mag(image, norm=5, eps=1e-3):
+    """reference channels.py:30-37: fp32 gradient magnitude, divided by its triangle-filtered
+    self (+eps); one channel."""
+    gx, gy = gradients(image.astype("f"))
+    mag = np.sqrt(gx ** 2 + gy ** 2)
+    if norm is not None and norm > 1:
+        H = triangle_kernel(norm)
+        nrm = _conv_sym(_conv_sym(mag, H, 0), H, 1)
+        mag = mag / (nrm + np.float32(eps))
+    return mag[..., None]
+
+
+def _sobel_int(arr):
+    """reference fpga/channels.py:5-27: the two 3x3 numba stencils.  Numba promotes the uint8
+    elements to int64 for scalar arithmetic (no wrap) and leaves the 1-pixel output border 0."""
+    a = arr.astype(np.int64)
+    u, v = a.shape
+    dx = np.zeros((u, v), np.int64)
+    dy = np.zeros((u, v), np.int64)
+    if u >= 3 and v >= 3:
+        def sh(dr, dc):
+            return a[1 + dr:u - 1 + dr, 1 + dc:v - 1 + dc]
+        dx[1:-1, 1:-1] = -(sh(-1, -1) + 2 * sh(0, -1) + sh(1, -1)) + sh(-1, 1) + 2 * sh(0, 1) + sh(1, 1)
+        dy[1:-1, 1:-1] = -(sh(-1, -1) + 2 * sh(-1, 0) + sh(-1, 1)) + sh(1, -1) + 2 * sh(1, 0) + sh(1, 1)
+    return dx, dy
+
+
+def grad_hist_4_u1(arr):
+    """reference fpga/channels.py:29-53: 4 integer orientation channels, uint8.
+    y1/y3 are fp64 halves stored into int32 (truncation toward zero); |y| // 4 clamped to 255."""
+    dx, dy = _sobel_int(arr)
+    y = np.empty(arr.shape + (4,), np.int32)
+    y[..., 0] = dx
+    y[..., 1] = np.trunc(0.5 * dx - 0.5 * dy)
+    y[..., 2] = dy
+    y[..., 3] = np.trunc(0.5 * dx + 0.5 * dy)
+    return np.fmin(np.abs(y) // 4, 255).astype(np.uint8)
+
+
+def grad_mag_u1(arr):
+    """reference fpga/channels.py:56-67: max(|dx|, |dy|) // 4 clamped to 255, one uint8 channel."""
+    dx, dy = _sobel_int(arr)
+    y = np.maximum(np.abs(dx), np.abs(dy)).astype(np.int32)[..., None]
+    return np.fmin(y // 4, 255).astype(np.uint8)
+
+
+CHANNEL_FUNCS = {"grad_hist": grad_hist, "grad_mag": grad_mag, "grad_hist_4_u1": grad_hist_4_u1,
+                 "grad_mag_u1": grad_mag_u1}
+
+
 # --------------------------------------------------------------------------- S9 smooth
 def smooth_image_3d(arr):
     """reference channels.py:78-90 with numba stencil semantics (S9):
@@ -250,6 +330,8 @@ def channel_pyramid(image, channel_opts):
     n_per_oct = channel_opts["n_per_oct"]
     smooth = channel_opts["smooth"]
     channels = channel_opts.get("channels", grad_hist)
+    if isinstance(channels, str):
+        channels = CHANNEL_FUNCS[channels]
     assert shrink in [1, 2, 4], "shrink must be 1, 2 (reference) or 4 (extension)"
     factor = 2 ** (-1 / n_per_oct)
     for base in image_octaves(image):

@@ -1,0 +1,155 @@
+"""GPU parity of the other channel functions the reference ships:
+waldboost.fpga.grad_hist_4_u1 / grad_mag_u1 as channel_opts["channels"] -- uint8 channels through
+the channel kernel and the cascade -- against fixtures generated from the reference's own source
+(tests/golden/make_golden_f2.py) and against the CPU oracle.  Everything is integer: bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import waldboost_amd as wb
+from oracle import wb_oracle as orc
+from waldboost_amd.synth import synth_image, random_tree_arrays
+from util import GOLDEN, f2_cases, f2_meta, oracle_detect
+
+pytestmark = pytest.mark.gpu
+
+FUNCS = {"grad_hist_4_u1": wb.fpga.grad_hist_4_u1, "grad_mag_u1": wb.fpga.grad_mag_u1}
+U1_CASES = [c for c in f2_cases() if c[2]["channels"] in FUNCS]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("case", U1_CASES, ids=lambda c: c[0])
+def test_u1_pyramid_bit_exact_vs_reference_fixture(case):
+    name, img, info, levels = case
+    opts = dict(shrink=info["shrink"], n_per_oct=info["n_per_oct"], smooth=info["smooth"], channels=FUNCS[info["channels"]])
+    got = list(wb.channels.channel_pyramid(img, opts))
+    assert len(got) == info["n_levels"]
+    for i, ((c, s), ref, rs) in enumerate(zip(got, levels, info["scales"])):
+        assert c.dtype == np.uint8 and c.shape == ref.shape, (name, i)
+        assert s == rs
+        assert np.array_equal(c, ref), (name, i, np.abs(c.astype(int) - ref).max())
+
+
+@pytest.mark.parametrize("fn", sorted(FUNCS))
+@pytest.mark.parametrize("shape,shrink", [((8, 8), 2), ((9, 23), 2), ((131, 97), 2), ((480, 640), 2), ((150, 211), 1),
+                                          ((200, 300), 4)])
+def test_u1_pyramid_vs_oracle(fn, shape, shrink):
+    img = synth_image(shape[0], shape[1], 31)
+    # half the pixels pushed to the extremes: gradients large enough to hit the 255 clamp and the pool wrap
+    rng = np.random.default_rng(3)
+    img = np.where(rng.random(shape) < 0.3, rng.choice(np.array([0, 255], np.uint8), shape), img).astype(np.uint8)
+    o = dict(shrink=shrink, n_per_oct=4 if shrink != 2 else 8, smooth=1)
+    got = list(wb.channels.channel_pyramid(img, dict(o, channels=FUNCS[fn])))
+    ref = list(orc.channel_pyramid(img, dict(o, channels=fn)))
+    assert len(got) == len(ref)
+    for (c, s), (rc, rs) in zip(got, ref):
+        assert s == rs and c.shape == rc.shape and c.dtype == rc.dtype == np.uint8
+        assert np.array_equal(c, rc)
+
+
+@pytest.mark.parametrize("fn", sorted(FUNCS))
+def test_u1_function_on_a_bare_image(fn):
+    img = synth_image(77, 103, 9)
+    got = FUNCS[fn](img)
+    ref = orc.CHANNEL_FUNCS[fn](img)
+    assert got.dtype == np.uint8 and got.shape == ref.shape and np.array_equal(got, ref)
+    assert (got[0] == 0).all() and (got[:, -1] == 0).all()         # numba stencil border
+    with pytest.raises(NotImplementedError):
+        FUNCS[fn](img.astype(np.float32))
+    with pytest.raises(ValueError):
+        FUNCS[fn](np.zeros((4, 4, 1), np.uint8))
+
+
+@pytest.mark.parametrize("fn", sorted(FUNCS))
+def test_u1_detect_vs_reference_fixture(fn):
+    meta = f2_meta()
+    g = np.load(os.path.join(GOLDEN, f"{fn}_200x264.npz"))
+    M = wb.load(os.path.join(GOLDEN, f"{fn}_d2_T24.pb"))
+    assert M.channel_opts["channels"] is FUNCS[fn]
+    assert wb.model.symbol_name(M.channel_opts["channels"]) == meta["names"][fn]
+    res = M.detect_raw(g["image"])
+    det = g["det"]
+    assert det.size > 0
+    assert M.n_loc == int(g["n_loc"]) and M.n_weak == int(g["n_weak"])
+    assert np.array_equal(res["alive"], g["alive"])
+    assert np.array_equal(res["level"], det["level"]) and np.array_equal(res["r"], det["r"]) and np.array_equal(res["c"], det["c"])
+    assert np.array_equal(bits(res["scores"]), bits(det["score"]))
+    assert np.array_equal(bits(res["boxes"]), bits(np.stack([det["x1"], det["y1"], det["x2"], det["y2"]], 1)))
+    # level-by-level through the reference-shaped surface: uint8 channel arrays into predict_on_image
+    M.reset()
+    rows = []
+    for li, (chns, scale, (r, c, h)) in enumerate(M.scan_channels(g["image"])):
+        assert chns.dtype == np.uint8
+        rows += [(li, int(a), int(b)) for a, b in zip(r, c)]
+    assert rows == [(int(d["level"]), int(d["r"]), int(d["c"])) for d in det]
+    assert M.n_weak == int(g["n_weak"])
+
+
+def u1_model(fn, seed, T, depth, lo, hi, sa=-0.45, sb=-0.15):
+    rng = np.random.default_rng(seed)
+    C = 4 if fn == "grad_hist_4_u1" else 1
+    shape = (12, 12, C)
+    M = wb.Model(shape, dict(shrink=2, n_per_oct=8, smooth=1, channels=FUNCS[fn]))
+    acc = 0.0
+    for t in range(T):
+        d = depth if depth else int(rng.integers(1, 4))
+        f, th, l, r, p = random_tree_arrays(rng, shape, d, lo, hi)
+        if t % 3 == 0:
+            th = np.round(th)                 # integer thresholds: the `<=` ties of uint8 values are exercised
+        acc += sb if t % 3 else sa
+        M.append(wb.DTree(f, th, l, r, p), float("-inf") if t % 5 == 4 else float(np.float32(acc)))
+    return M
+
+
+@pytest.mark.parametrize("fn", sorted(FUNCS))
+@pytest.mark.parametrize("depth", [1, 2, 0])
+def test_u1_detect_vs_oracle(fn, depth):
+    img = synth_image(300, 420, 17)
+    M = u1_model(fn, 5 + depth, 40, depth, 1.0, 20.0)
+    res = M.detect_raw(img)
+    ref = oracle_detect(M, img)
+    assert ref["scores"].size > 0
+    assert np.array_equal(res["alive"], ref["alive"])
+    assert np.array_equal(res["level"], ref["level"])
+    assert np.array_equal(res["r"], ref["r"]) and np.array_equal(res["c"], ref["c"])
+    assert np.array_equal(bits(res["scores"]), bits(ref["scores"]))
+    assert np.array_equal(bits(res["boxes"]), bits(ref["boxes"]))
+    assert M.n_loc == ref["n_loc"] and M.n_weak == ref["n_weak"]
+
+
+def test_u1_batch_and_tree_eval():
+    fn = "grad_hist_4_u1"
+    M = u1_model(fn, 9, 24, 2, 1.0, 20.0)
+    imgs = np.stack([synth_image(240, 320, s) for s in (1, 2, 3)])
+    res = M.detect_batch_raw(imgs)
+    for b in range(3):
+        ref = oracle_detect(M, imgs[b])
+        sel = res["image"] == b
+        assert np.array_equal(res["r"][sel], ref["r"]) and np.array_equal(res["c"][sel], ref["c"])
+        assert np.array_equal(bits(res["scores"][sel]), bits(ref["scores"]))
+        assert np.array_equal(res["alive"][b], ref["alive"])
+    # DTree.predict_on_image on a uint8 channel image
+    chns, _ = next(iter(wb.channels.channel_pyramid(imgs[0], M.channel_opts)))
+    rs, cs = np.indices((chns.shape[0] - 12, chns.shape[1] - 12))
+    rs, cs = rs.flatten()[::7], cs.flatten()[::7]
+    w = M.classifier[3]
+    got = w.predict_on_image(chns, rs, cs)
+    ref = orc.tree_predict_on_image(orc.make_tree(w.feature, w.threshold, w.left, w.right, w.prediction), chns, rs, cs)
+    assert np.array_equal(bits(got), bits(ref))
+
+
+def test_u1_1080p_vs_oracle():
+    """Full-size frame, 64-stage depth-2 cascade over uint8 channels."""
+    img = synth_image(1080, 1920, 0)
+    M = u1_model("grad_hist_4_u1", 21, 64, 2, 1.0, 20.0, 0.05, 0.02)
+    res = M.detect_raw(img)
+    ref = oracle_detect(M, img)
+    assert ref["n_loc"] == 3045278
+    assert np.array_equal(res["alive"], ref["alive"])
+    assert np.array_equal(res["r"], ref["r"]) and np.array_equal(res["c"], ref["c"]) and np.array_equal(res["level"], ref["level"])
+    assert np.array_equal(bits(res["scores"]), bits(ref["scores"]))

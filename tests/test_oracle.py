@@ -10,7 +10,7 @@ import scipy.ndimage as ndi
 import waldboost_amd as wb
 from oracle import wb_oracle as orc
 from waldboost_amd.synth import synth_image
-from util import GOLDEN, golden_meta, oracle_detect, small_cases
+from util import GOLDEN, f2_cases, f2_meta, golden_meta, oracle_detect, small_cases
 
 
 def sha(a):
@@ -77,6 +77,71 @@ def test_empty_model_keeps_every_window():
     res = orc.detect((12, 12, 4), opts, [], [], g["image"])
     assert np.array_equal(res["boxes"], g["boxes"]) and np.array_equal(res["scores"], g["scores"])
     assert res["n_loc"] == int(g["n_loc"]) and res["n_weak"] == 0
+
+
+# ---- the other channel functions: fpga.grad_hist_4_u1 / grad_mag_u1, grad_mag ----
+@pytest.mark.parametrize("case", list(f2_cases()), ids=lambda c: c[0])
+def test_f2_pyramid_matches_reference_bit_exact(case):
+    name, img, info, levels = case
+    opts = dict(shrink=info["shrink"], n_per_oct=info["n_per_oct"], smooth=info["smooth"], channels=info["channels"])
+    got = list(orc.channel_pyramid(img, opts))
+    assert len(got) == info["n_levels"]
+    for (c, s), ref, rs in zip(got, levels, info["scales"]):
+        assert c.dtype == ref.dtype == np.dtype(info["dtype"]) and c.shape == ref.shape
+        assert s == rs
+        assert np.array_equal(c.view(np.uint8), ref.view(np.uint8))
+
+
+def test_f2_uint8_channel_pool_wraps():
+    """The 'edgy' fixtures exist to exercise the uint8 wrap of avg_pool_2 on channel values."""
+    for name, img, info, levels in f2_cases():
+        if "edgy" in name and info["shrink"] == 2 and info["smooth"] == 0:
+            full = orc.CHANNEL_FUNCS[info["channels"]](orc.resize_bilinear(img, *[2 * x for x in levels[0].shape[:2]]))
+            s = full[0::2, 0::2].astype(np.int32) + full[1::2, 0::2] + full[0::2, 1::2] + full[1::2, 1::2]
+            assert (s > 255).any(), name
+            return
+    raise AssertionError("no wrapping fixture")
+
+
+@pytest.mark.parametrize("fn", ["grad_hist_4_u1", "grad_mag_u1", "grad_mag"])
+def test_f2_detect_matches_reference(fn):
+    meta = f2_meta()
+    g = np.load(os.path.join(GOLDEN, f"{fn}_200x264.npz"))
+    proto = wb.model_pb2.Model()
+    import zlib
+    proto.ParseFromString(zlib.decompress(open(os.path.join(GOLDEN, f"{fn}_d2_T24.pb"), "rb").read()))
+    assert proto.channel_opts.func == meta["names"][fn]
+    trees = [orc.make_tree(np.array(w.feature, np.uint8).reshape(-1, 3), np.array(w.threshold, np.float32),
+                           np.array(w.left, np.int8), np.array(w.right, np.int8), np.array(w.prediction, np.float32))
+             for w in proto.classifier]
+    opts = dict(shrink=proto.channel_opts.shrink, n_per_oct=proto.channel_opts.n_per_oct,
+                smooth=proto.channel_opts.smooth, channels=fn)
+    hashes = [sha(c) for c, _ in orc.channel_pyramid(g["image"], opts)]
+    assert hashes == meta[fn]["chn_sha256"]
+    res = orc.detect(tuple(proto.shape), opts, trees, list(proto.theta), g["image"])
+    det = g["det"]
+    assert res["n_loc"] == int(g["n_loc"]) and res["n_weak"] == int(g["n_weak"])
+    assert np.array_equal(res["alive"], g["alive"])
+    assert np.array_equal(res["r"], det["r"]) and np.array_equal(res["c"], det["c"]) and np.array_equal(res["level"], det["level"])
+    assert np.array_equal(res["scores"].view(np.uint32), det["score"].view(np.uint32))
+    assert np.array_equal(res["boxes"], np.stack([det["x1"], det["y1"], det["x2"], det["y2"]], 1))
+
+
+def test_grad_mag_equals_scipy():
+    from scipy.ndimage import convolve1d
+    rng = np.random.default_rng(5)
+    for shape in [(37, 53), (8, 9), (3, 3), (120, 7)]:
+        img = rng.integers(0, 256, shape).astype(np.uint8)
+        im = img.astype("f")
+        H, D = np.array([1, 2, 1], "f4"), np.array([-1, 0, 1], "f4")
+        gy = convolve1d(convolve1d(im, H, axis=1), D, axis=0)
+        gx = convolve1d(convolve1d(im, H, axis=0), D, axis=1)
+        mag = np.sqrt(gx ** 2 + gy ** 2)
+        K = orc.triangle_kernel(5)
+        nrm = convolve1d(mag, K, axis=0)
+        convolve1d(nrm, K, axis=1, output=nrm)
+        mag /= nrm + 1e-3
+        assert np.array_equal(orc.grad_mag(img).view(np.uint32), mag[..., None].view(np.uint32))
 
 
 # ---- SciPy known-answer tests (SciPy ships on the GPU box as well) -------------------------

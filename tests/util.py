@@ -17,8 +17,9 @@ def golden_meta():
 def oracle_model(M):
     """(shape, opts, trees, thetas) of a waldboost_amd.Model in the oracle's plain-array form."""
     trees = [orc.make_tree(w.feature, w.threshold, w.left, w.right, w.prediction) for w in M.classifier]
+    from waldboost_amd.channels import channel_spec
     opts = dict(M.channel_opts)
-    opts["channels"] = orc.grad_hist
+    opts["channels"] = orc.CHANNEL_FUNCS[channel_spec(M.channel_opts["channels"]).key]
     return tuple(M.shape), opts, trees, list(M.theta)
 
 
@@ -35,6 +36,21 @@ def det_table(res):
 def small_cases():
     meta = golden_meta()["cases"]
     z = np.load(os.path.join(GOLDEN, "pyramids_small.npz"))
+    for name, info in meta.items():
+        img = z[f"{name}/image"]
+        levels = [z[f"{name}/L{i}"] for i in range(info["n_levels"])]
+        yield name, img, info, levels
+
+
+def f2_meta():
+    with open(os.path.join(GOLDEN, "golden_meta_f2.json")) as f:
+        return json.load(f)
+
+
+def f2_cases():
+    """Small pyramids of the other channel functions (tests/golden/make_golden_f2.py)."""
+    meta = f2_meta()["cases"]
+    z = np.load(os.path.join(GOLDEN, "pyramids_f2.npz"))
     for name, info in meta.items():
         img = z[f"{name}/image"]
         levels = [z[f"{name}/L{i}"] for i in range(info["n_levels"])]

@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libwaldboost_hip.so")
 WB_DTYPE_U8, WB_DTYPE_F32 = 0, 1
 WB_ERR_INVALID, WB_ERR_HIP, WB_ERR_UNSUPPORTED = -1, -2, -3
 WB_DET_SHARDS = 64
+WB_CHN_GRAD_HIST, WB_CHN_GRAD_HIST_4_U1, WB_CHN_GRAD_MAG_U1, WB_CHN_GRAD_MAG = 0, 1, 2, 3
+WB_ABI_VERSION = 2
 
 # numpy mirrors of the ABI structs (sizes asserted against the header's comments)
 LEVEL_DTYPE = np.dtype([
@@ -38,16 +40,17 @@ SYMBOLS = {
     "wb_abi_version": (C.c_int, []),
     "wb_last_error": (C.c_char_p, []),
     "wb_channels_tile": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "wb_channel_func_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "wb_octaves_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, C.c_int64,
                                     C.POINTER(C.c_int64), C.c_int, _P]),
     "wb_channels_launch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int,
-                                     _P, C.c_int, _P, C.c_int, C.c_int, C.POINTER(C.c_double), _P, C.c_int64]),
+                                     _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P, C.c_int64]),
     "wb_model_create": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "wb_model_destroy": (C.c_int, [_P]),
     "wb_model_info": (C.c_int, [_P, C.POINTER(WbModelInfo)]),
-    "wb_cascade_launch": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P,
+    "wb_cascade_launch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P,
                                     C.c_uint32, _P, _P]),
-    "wb_tree_eval_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P, _P, _P, _P, _P,
+    "wb_tree_eval_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P, _P, _P, _P, _P,
                                       C.c_int, _P]),
     "wb_boxes_launch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int, C.c_int, _P, _P]),
     "wb_selftest_projection": (C.c_int, [_P, _P]),
@@ -77,7 +80,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.wb_abi_version() != 1:
+    if lib.wb_abi_version() != WB_ABI_VERSION:
         raise NativeError("libwaldboost_hip.so ABI version mismatch")
     _lib = lib
     return lib

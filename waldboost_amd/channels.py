@@ -1,14 +1,19 @@
 """Channel features / pyramid -- drop-in for ``waldboost.channels`` on the hot path.
 
 ``channel_pyramid(image, channel_opts)`` keeps the reference signature and yields the same
-``(chns[u,v,C] float32, scale)`` pairs (reference channels.py:111-146), computed by the fused
-HIP kernel in csrc/wb_channels.hip; ``grad_hist(image)`` is reference channels.py:40-52 for
-its default arguments (n_bins=4, full=False, bias=0).
+``(chns[u,v,C], scale)`` pairs (reference channels.py:111-146), computed by the fused HIP
+kernels in csrc/wb_channels.hip.  Channel functions with a kernel:
+
+  ``grad_hist(image)``            reference channels.py:40-52, default arguments
+                                  (n_bins=4, full=False, bias=0)          -> float32 [H,W,4]
+  ``fpga.grad_hist_4_u1(image)``  reference fpga/channels.py:29-53        -> uint8   [H,W,4]
+  ``fpga.grad_mag_u1(image)``     reference fpga/channels.py:56-67        -> uint8   [H,W,1]
 """
 import numpy as np
 
 from . import _native as nat
 from . import engine as _engine
+from .chanfunc import SPECS, ChannelSpec  # noqa: F401
 
 
 def _validate_image(image):
@@ -19,47 +24,93 @@ def _validate_image(image):
         raise ValueError("Image must have 2 dimensions")
 
 
-def grad_hist(image, n_bins=4, full=False, bias=0):
-    """4 unsigned oriented-gradient channels of a 2-D image -> float32 [H,W,4]."""
-    if n_bins != 4 or full or bias != 0:
-        raise NotImplementedError("the HIP grad_hist kernel implements the defaults n_bins=4, full=False, bias=0")
+def _on_bare_image(image, spec):
+    """A channel function applied to one image (no pyramid, no resize): a single-level engine."""
     _validate_image(image)
-    img = np.ascontiguousarray(image.astype("f"))
-    H, W = img.shape
+    H, W = image.shape
     if H < 1 or W < 1:
-        return np.empty((H, W, 4), np.float32)
-    eng = _engine.get_engine(H, W, np.float32, 1, 1, 0, 1, exact_single=True)
+        return np.empty((H, W, spec.n_channels), spec.dtype)
+    img = np.ascontiguousarray(image)
+    eng = _engine.get_engine(H, W, img.dtype, 1, 1, 0, 1, exact_single=True, channels=spec)
     eng.load_images(img)
     eng.run_channels()
     return eng.read_level(0, 0)
 
 
+def grad_hist(image, n_bins=4, full=False, bias=0):
+    """4 unsigned oriented-gradient channels of a 2-D image -> float32 [H,W,4]."""
+    if n_bins != 4 or full or bias != 0:
+        raise NotImplementedError("the HIP grad_hist kernel implements the defaults n_bins=4, full=False, bias=0")
+    _validate_image(image)
+    return _on_bare_image(image.astype("f"), SPECS["grad_hist"])
+
+
+def grad_hist_4_u1(image):
+    """8 bit image -> 4 integer orientation channels, uint8 [H,W,4] (reference fpga/channels.py:29-53)."""
+    _validate_image(image)
+    _require_u8(image, "grad_hist_4_u1")
+    return _on_bare_image(image, SPECS["grad_hist_4_u1"])
+
+
+def grad_mag_u1(image):
+    """8 bit image -> max(|dx|, |dy|) // 4, uint8 [H,W,1] (reference fpga/channels.py:56-67)."""
+    _validate_image(image)
+    _require_u8(image, "grad_mag_u1")
+    return _on_bare_image(image, SPECS["grad_mag_u1"])
+
+
+def _require_u8(image, name):
+    if image.dtype != np.uint8:
+        raise NotImplementedError(f"{name} takes 8 bit images (uint8), got {image.dtype}; "
+                                  "other dtypes have no HIP kernel")
+
+
+SPECS["grad_hist"].func = grad_hist
+SPECS["grad_hist_4_u1"].func = grad_hist_4_u1
+SPECS["grad_mag_u1"].func = grad_mag_u1
+
 # Names a stored model may use for its channel function (reference model.py:302 writes
 # module.qualname; model.py:27-29 evals it on load -- replaced here by this allow-list).
-CHANNEL_FUNCS = {
-    "waldboost.channels.grad_hist": grad_hist,
-    "waldboost_amd.channels.grad_hist": grad_hist,
-}
+CHANNEL_FUNCS = {}
+for _spec in SPECS.values():
+    CHANNEL_FUNCS[_spec.reference_name] = _spec.func
+    CHANNEL_FUNCS["waldboost_amd.channels." + _spec.key] = _spec.func
+CHANNEL_FUNCS["waldboost.fpga.grad_hist_4_u1"] = grad_hist_4_u1
+CHANNEL_FUNCS["waldboost.fpga.grad_mag_u1"] = grad_mag_u1
+CHANNEL_FUNCS["waldboost_amd.fpga.grad_hist_4_u1"] = grad_hist_4_u1
+CHANNEL_FUNCS["waldboost_amd.fpga.grad_mag_u1"] = grad_mag_u1
+
+
+def channel_spec(func):
+    """The ChannelSpec of a channel function: ours, or the reference's own function object
+    (recognised by module and qualified name); None if it has no kernel."""
+    for spec in SPECS.values():
+        if func is spec.func:
+            return spec
+    name = getattr(func, "__module__", "") + "." + getattr(func, "__qualname__", "")
+    for spec in SPECS.values():
+        if name == spec.reference_name:
+            return spec
+    return None
 
 
 def is_grad_hist(func):
-    if func is grad_hist:
-        return True
-    name = getattr(func, "__module__", "") + "." + getattr(func, "__qualname__", "")
-    return name == "waldboost.channels.grad_hist"     # the reference's own function object
+    return channel_spec(func) is SPECS["grad_hist"]
 
 
 def read_opts(channel_opts):
+    """(shrink, n_per_oct, smooth, spec) of a channel_opts dict (reference channels.py:116-120)."""
     shrink = channel_opts["shrink"]
     n_per_oct = channel_opts["n_per_oct"]
     smooth = channel_opts["smooth"]
     channels = channel_opts["channels"]
     assert shrink in [1, 2, 4], "Shrink factor must be integer 1 <= shrink <= 2 (4: extension of this build)"
-    if not is_grad_hist(channels):
-        raise NotImplementedError(f"channel function {channels!r} has no HIP kernel (grad_hist only)")
+    spec = channel_spec(channels)
+    if spec is None:
+        raise NotImplementedError(f"channel function {channels!r} has no HIP kernel (known: {sorted(SPECS)})")
     if smooth not in (0, 1):
         smooth = 0          # the reference smooths only when smooth == 1 (channels.py:141)
-    return int(shrink), int(n_per_oct), int(smooth)
+    return int(shrink), int(n_per_oct), int(smooth), spec
 
 
 def channel_pyramid(image, channel_opts):
@@ -68,9 +119,11 @@ def channel_pyramid(image, channel_opts):
     The whole pyramid is computed on the GPU in one launch group when the first level is
     requested; levels are copied to the host one by one as they are consumed."""
     _validate_image(image)
-    shrink, n_per_oct, smooth = read_opts(channel_opts)
+    shrink, n_per_oct, smooth, spec = read_opts(channel_opts)
+    if spec.dtype == np.uint8:
+        _require_u8(image, spec.key)
     H, W = image.shape
-    eng = _engine.get_engine(H, W, image.dtype, shrink, n_per_oct, smooth, 1)
+    eng = _engine.get_engine(H, W, image.dtype, shrink, n_per_oct, smooth, 1, channels=spec)
     if eng.plan.n_levels == 0:
         return
     eng.load_images(image)

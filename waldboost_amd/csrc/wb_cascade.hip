@@ -38,7 +38,8 @@
 namespace {
 
 struct CascArgs {
-    const float *chn;
+    const void *chn;            // [u][v][C] float32, or uint8 when chn_u8
+    int chn_u8;
     int64_t chn_stride;
     const WbLevel *levels;
     const WbTile *tiles;
@@ -179,8 +180,42 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     for (int i = tid; i < a.lds_stages * (SD / 4); i += NT) stab[i] = reinterpret_cast<const int4 *>(stages)[i];
 
     // ---- stage the channel block into LDS (planar [C][rows][pitch])
-    const float *chn = a.chn + (int64_t)b * a.chn_stride + L.chn_off;
+    const float *chn = reinterpret_cast<const float *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
+    const uint8_t *chn8 = reinterpret_cast<const uint8_t *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
     if (a.dbg & 1) {
+    } else if (a.chn_u8 && a.C == 4) {
+        // uint8 channels, one dword per pixel: same batched scheme as the float4 path below; the
+        // four bytes are widened to their exact float32 values on the way into the LDS planes
+        // (uint8 <= float32 compares in float32 under NumPy promotion), so the stage loop is unchanged
+        constexpr int U = 8;
+        const int ncol = WB_CASC_TC + a.n - 1;
+        const int total = rows * ncol;
+        const uint32_t m_ncol = 0xFFFFFFFFu / (uint32_t)ncol + 1u;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(chn8);
+        const int plane = rows * pitch;
+        for (int e0 = tid; e0 < total; e0 += NT * U) {
+            uint32_t v[U];
+            int dst[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                uint32_t e = (uint32_t)(e0 + k * NT);
+                const bool in = e < (uint32_t)total;
+                e = in ? e : (uint32_t)total - 1u;
+                uint32_t row = __umulhi(e, m_ncol), col = e - row * (uint32_t)ncol;
+                int gr = r0 + (int)row, gc = c0 + (int)col;
+                gr = gr < L.u ? gr : L.u - 1;
+                gc = gc < L.v ? gc : L.v - 1;
+                v[k] = src[(int64_t)gr * L.v + gc];
+                dst[k] = in ? (int)(row * (uint32_t)pitch + col) : plane - 1;
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                tile[dst[k]] = (float)(v[k] & 255u);
+                tile[dst[k] + plane] = (float)((v[k] >> 8) & 255u);
+                tile[dst[k] + 2 * plane] = (float)((v[k] >> 16) & 255u);
+                tile[dst[k] + 3 * plane] = (float)(v[k] >> 24);
+            }
+        }
     } else if (a.C == 4) {
         // Channels live in HBM as one float4 per pixel ([u][v][4]): a tile row is ONE contiguous
         // run of (64+n-1)*16 bytes.  Each thread loads U pixels back to back (straight-line code:
@@ -226,7 +261,10 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
             int col = rc % pitch, row = rc / pitch;
             int gr = r0 + row, gc = c0 + col;
             float v = 0.f;
-            if (gr < L.u && gc < L.v) v = chn[((int64_t)gr * L.v + gc) * a.C + ch];
+            if (gr < L.u && gc < L.v) {
+                const int64_t at = ((int64_t)gr * L.v + gc) * a.C + ch;
+                v = a.chn_u8 ? (float)chn8[at] : chn[at];
+            }
             tile[(ch * rows + row) * pitch + col] = v;
         }
     }
@@ -474,7 +512,8 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
 // so the per-stage alive counts are ballots; survivors leave through an LDS list and one sharded
 // atomic per workgroup, like the tiled kernel.  Correctness fallback, not a tuned path.
 struct GenArgs {
-    const float *chn;
+    const void *chn;
+    int chn_u8;
     int64_t chn_stride;
     const WbLevel *levels;
     const WbTile *tiles;
@@ -502,7 +541,8 @@ __global__ __launch_bounds__(256) void cascade_generic_kernel(GenArgs a) {
     for (int t = tid; t < a.T; t += 256) hist[t] = 0;
     if (tid == 0) n_list = 0;
     __syncthreads();
-    const float *chn = a.chn + (int64_t)b * a.chn_stride + L.chn_off;
+    const float *chn = reinterpret_cast<const float *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
+    const uint8_t *chn8 = reinterpret_cast<const uint8_t *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
     bool alive = r < nr && c < nc;
     float h = 0.f;
     for (int t = 0; t < a.T; ++t) {
@@ -516,7 +556,8 @@ __global__ __launch_bounds__(256) void cascade_generic_kernel(GenArgs a) {
                 int l = a.left[o + node];
                 if (l < 0) break;
                 int f = a.feat[o + node];
-                float v = chn[((int64_t)(r + (f & 255)) * L.v + (c + ((f >> 8) & 255))) * a.C + ((f >> 16) & 255)];
+                const int64_t at = ((int64_t)(r + (f & 255)) * L.v + (c + ((f >> 8) & 255))) * a.C + ((f >> 16) & 255);
+                float v = a.chn_u8 ? (float)chn8[at] : chn[at];
                 node = (v <= a.thr[o + node]) ? l : a.right[o + node];
             }
             h = h + a.pred[o + node];
@@ -580,7 +621,7 @@ __global__ __launch_bounds__(1024) void alive_reduce_kernel(const uint32_t *tile
 
 // -------------------------------------------------------------------------------------------
 // DTree.predict_on_image on explicit window lists (reference training.py:84-96)
-__global__ void tree_eval_kernel(const float *X, int u, int v, int C, const int32_t *rs, const int32_t *cs,
+__global__ void tree_eval_kernel(const void *Xv, int x_u8, int u, int v, int C, const int32_t *rs, const int32_t *cs,
                                  int64_t n_pos, const uint8_t *feature, const float *threshold,
                                  const int8_t *left, const int8_t *right, const float *prediction,
                                  int n_nodes, float *out) {
@@ -592,7 +633,8 @@ __global__ void tree_eval_kernel(const float *X, int u, int v, int C, const int3
         int l = left[node];
         if (l < 0) break;
         int fr = feature[node * 3 + 0], fc = feature[node * 3 + 1], ch = feature[node * 3 + 2];
-        float val = X[((int64_t)(r + fr) * v + (c + fc)) * C + ch];
+        const int64_t at = ((int64_t)(r + fr) * v + (c + fc)) * C + ch;
+        float val = x_u8 ? (float)reinterpret_cast<const uint8_t *>(Xv)[at] : reinterpret_cast<const float *>(Xv)[at];
         node = (val <= threshold[node]) ? l : (int)right[node];
     }
     out[i] = prediction[node];
@@ -658,8 +700,8 @@ int wb_cascade_prepare(int depth, int rpw, int waves) {
     return WB_ERR_UNSUPPORTED;
 }
 
-extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const float *chn, int64_t chn_stride,
-                                 int batch, const WbLevel *levels, int n_levels,
+extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void *chn, int chn_dtype,
+                                 int64_t chn_stride, int batch, const WbLevel *levels, int n_levels,
                                  const WbTile *tiles, const int32_t *tile_csr, int n_tiles, WbDet *det,
                                  uint32_t *det_count, uint32_t shard_capacity, uint32_t *tile_hist,
                                  uint32_t *alive) {
@@ -668,8 +710,10 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const float
     WB_REQUIRE(det || shard_capacity == 0, "wb_cascade_launch: det is null but capacity > 0");
     WB_REQUIRE(batch >= 1 && batch <= 65535, "wb_cascade_launch: batch %d out of range", batch);
     WB_REQUIRE(n_levels >= 1 && n_tiles >= 1, "wb_cascade_launch: empty launch");
+    WB_REQUIRE(chn_dtype == WB_DTYPE_F32 || chn_dtype == WB_DTYPE_U8, "wb_cascade_launch: channel dtype %d (float32 or uint8)", chn_dtype);
     CascArgs a;
     a.chn = chn;
+    a.chn_u8 = chn_dtype == WB_DTYPE_U8;
     a.chn_stride = chn_stride;
     a.levels = levels;
     a.tiles = tiles;
@@ -695,7 +739,7 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const float
     hipStream_t st = (hipStream_t)stream;
     if (model->generic) {
         GenArgs g;
-        g.chn = chn; g.chn_stride = chn_stride; g.levels = levels; g.tiles = tiles;
+        g.chn = chn; g.chn_u8 = a.chn_u8; g.chn_stride = chn_stride; g.levels = levels; g.tiles = tiles;
         g.n_levels = n_levels; g.n_tiles = n_tiles;
         g.T = model->n_stages; g.m = model->m; g.n = model->n; g.C = model->C;
         g.node_off = model->g_node_off; g.feat = model->g_feat; g.left = model->g_left; g.right = model->g_right;
@@ -719,7 +763,7 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const float
     return WB_ERR_UNSUPPORTED;
 }
 
-extern "C" int wb_tree_eval_launch(void *stream, const float *X, int u, int v, int C, const int32_t *rs,
+extern "C" int wb_tree_eval_launch(void *stream, const void *X, int x_dtype, int u, int v, int C, const int32_t *rs,
                                    const int32_t *cs, int64_t n_pos, const uint8_t *feature,
                                    const float *threshold, const int8_t *left, const int8_t *right,
                                    const float *prediction, int n_nodes, float *out) {
@@ -728,9 +772,10 @@ extern "C" int wb_tree_eval_launch(void *stream, const float *X, int u, int v, i
     WB_REQUIRE(X && rs && cs && feature && threshold && left && right && prediction && out,
                "wb_tree_eval_launch: null pointer");
     WB_REQUIRE(u > 0 && v > 0 && C > 0 && n_nodes > 0 && n_nodes <= 127, "wb_tree_eval_launch: bad shape");
+    WB_REQUIRE(x_dtype == WB_DTYPE_F32 || x_dtype == WB_DTYPE_U8, "wb_tree_eval_launch: channel dtype %d (float32 or uint8)", x_dtype);
     int64_t blocks = (n_pos + 255) / 256;
-    hipLaunchKernelGGL(tree_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, u, v, C, rs,
-                       cs, n_pos, feature, threshold, left, right, prediction, n_nodes, out);
+    hipLaunchKernelGGL(tree_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X,
+                       (int)(x_dtype == WB_DTYPE_U8), u, v, C, rs, cs, n_pos, feature, threshold, left, right, prediction, n_nodes, out);
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;
 }

@@ -27,7 +27,7 @@ struct ChanArgs {
     const uint32_t *minmax;
     const WbTap *taps;
     int n_oct;
-    float *chn;
+    void *chn;           // [u][v][C] per level, dtype of the channel function
     int64_t chn_stride;
     double cs[4], sn[4];
     float chi, clo;      // sin(pi/4) = chi + clo (two-float split) for the integer-gradient fast path
@@ -134,45 +134,38 @@ __device__ inline void project_int(float gx, float gy, const ChanArgs &a, float 
     if (gx != 0.0f && (gy == 0.0f || d1 == 0.0f || d3 == 0.0f)) project_f64(gx, gy, a, out);
 }
 
-template <typename T, int S, int TU, int TV, bool SMOOTH, bool FAST>
-__global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
-    constexpr int HS = SMOOTH ? 1 : 0;
-    constexpr int SU = TU + 2 * HS, SV = TV + 2 * HS;  // shrunk tile incl. smooth halo
-    constexpr int RH = S * SU + 2, RW = S * SV + 2;    // resized tile incl. Sobel halo
-    constexpr int P = S + 2;                           // patch side per shrunk pixel
-
+// Tile geometry shared by the channel kernels: TU x TV outputs per workgroup, shrink S
+template <int S_, int TU_, int TV_, bool SMOOTH_> struct TileGeom {
+    static constexpr int S = S_, TU = TU_, TV = TV_;
+    static constexpr bool SMOOTH = SMOOTH_;
+    static constexpr int HS = SMOOTH ? 1 : 0;
+    static constexpr int SU = TU + 2 * HS, SV = TV + 2 * HS;  // shrunk tile incl. smooth halo
+    static constexpr int RH = S * SU + 2, RW = S * SV + 2;    // resized tile incl. the 3x3 gradient halo
+    static constexpr int P = S + 2;                           // patch side per shrunk pixel
     // LDS: R (resized tile) | one region shared by the uint8 source patch (live in step 1 only)
-    // and the shrunk tile Sh (live from step 2 on)
-    // source patch capacity: no larger than Sh, so that R + region stay under 40 KiB (4 workgroups
-    // per CU); tiles of the most down-scaled levels of an octave that do not fit take the direct path
-    constexpr int PROWS = 2 * RH + 4, PPITCH = ((SU * SV * 16) / PROWS) & ~3;
-    constexpr int SH_BYTES = SU * SV * 16;
-    constexpr int PATCH_BYTES = sizeof(T) == 1 ? PROWS * PPITCH : 0;
-    constexpr int UNI_BYTES = SH_BYTES > PATCH_BYTES ? SH_BYTES : PATCH_BYTES;
-    __shared__ float R[RH * RW];
-    __shared__ __attribute__((aligned(16))) unsigned char uni[UNI_BYTES];
-    F4 *Sh = reinterpret_cast<F4 *>(uni);
+    // and the shrunk tile Sh (live from step 2 on).  Source patch capacity: no larger than a
+    // float4 Sh, so that R + region stay under 40 KiB (4 workgroups per CU); tiles of the most
+    // down-scaled levels of an octave that do not fit take the direct path
+    static constexpr int PROWS = 2 * RH + 4, PPITCH = ((SU * SV * 16) / PROWS) & ~3;
+    static constexpr int SH_BYTES = SU * SV * 16;
+    static constexpr int PATCH_BYTES = PROWS * PPITCH;
+};
 
-    const WbTile tile = a.tiles[blockIdx.x];
-    const WbLevel L = a.levels[tile.level];
-    const int b = blockIdx.y;
-    const int tid = threadIdx.x;
-    const int u0 = tile.ty * TU, v0 = tile.tx * TV;
-
-    const T *src = (L.oct == 0) ? (const T *)a.img + (int64_t)b * a.img_stride
-                                : (const T *)a.oct + (int64_t)b * a.oct_stride + L.src_off;
-    const uint32_t *mm = a.minmax + ((int64_t)b * a.n_oct + L.oct) * 2;
-    const double mn = Src<T>::lo(~mm[0]), mx = Src<T>::lo(mm[1]);   // mm[0] holds max(~key)
-
-    const int ry0 = S * (u0 - HS) - 1, rx0 = S * (v0 - HS) - 1;
+// ---- step 1 of every channel kernel: bilinear resample of the tile (+ 1-pixel gradient halo) into
+//      R, cast back to the image dtype.
+//      One tile row per wave at a time: the row's taps are wave-uniform (scalar registers,
+//      scalar row base pointers), the column taps of a lane's NCS columns live in registers,
+//      and the 4*NCS source loads of a row are issued before any arithmetic.  Coordinates are
+//      clamped to the level = the 'reflect' halo of convolve1d for a 1-pixel border.
+//      The RW % 64 right-most columns are done afterwards, one pixel per thread.
+//      Ends without a barrier: the caller synchronises before reading R.
+template <typename T, typename G>
+__device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &L, const T *src, const double mn,
+                                              const double mx, const int ry0, const int rx0, float *R,
+                                              unsigned char *uni, const int tid) {
+    constexpr int RH = G::RH, RW = G::RW, PROWS = G::PROWS, PPITCH = G::PPITCH;
     const Tap *__restrict__ rtap = a.taps + L.tap_off;      // row taps [nh], then column taps [nw]
     const Tap *__restrict__ ctap = rtap + L.nh;
-    // ---- step 1: bilinear resample of the tile (+ Sobel halo) into R, cast back to the image dtype.
-    //      One tile row per wave at a time: the row's taps are wave-uniform (scalar registers,
-    //      scalar row base pointers), the column taps of a lane's NCS columns live in registers,
-    //      and the 4*NCS source loads of a row are issued before any arithmetic.  Coordinates are
-    //      clamped to the level = the 'reflect' halo of convolve1d for a 1-pixel border.
-    //      The RW % 64 right-most columns are done afterwards, one pixel per thread.
     constexpr int NCS = RW / 64, MAINW = NCS * 64, LEFT = RW - MAINW;
     const int lane = tid & 63, wave = tid >> 6;
     // Levels at their octave's own size (scale 1: every level i=0 with even dims) resample with
@@ -354,6 +347,31 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
             R[k * RW + q] = out;
         }
     }
+}
+
+template <typename T, int S, int TU, int TV, bool SMOOTH, bool FAST>
+__global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
+    using G = TileGeom<S, TU, TV, SMOOTH>;
+    constexpr int HS = G::HS, SU = G::SU, SV = G::SV, RH = G::RH, RW = G::RW, P = G::P;
+    constexpr int PATCH_BYTES = sizeof(T) == 1 ? G::PATCH_BYTES : 0;
+    constexpr int UNI_BYTES = G::SH_BYTES > PATCH_BYTES ? G::SH_BYTES : PATCH_BYTES;
+    __shared__ float R[RH * RW];
+    __shared__ __attribute__((aligned(16))) unsigned char uni[UNI_BYTES];
+    F4 *Sh = reinterpret_cast<F4 *>(uni);
+
+    const WbTile tile = a.tiles[blockIdx.x];
+    const WbLevel L = a.levels[tile.level];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int u0 = tile.ty * TU, v0 = tile.tx * TV;
+
+    const T *src = (L.oct == 0) ? (const T *)a.img + (int64_t)b * a.img_stride
+                                : (const T *)a.oct + (int64_t)b * a.oct_stride + L.src_off;
+    const uint32_t *mm = a.minmax + ((int64_t)b * a.n_oct + L.oct) * 2;
+    const double mn = Src<T>::lo(~mm[0]), mx = Src<T>::lo(mm[1]);   // mm[0] holds max(~key)
+
+    const int ry0 = S * (u0 - HS) - 1, rx0 = S * (v0 - HS) - 1;
+    resample_tile<T, G>(a, L, src, mn, mx, ry0, rx0, R, uni, tid);
     __syncthreads();
     if (a.dbg & 1) return;
 
@@ -418,7 +436,7 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
     //      it needs is read and widened to fp64 once for up to three output rows.
     constexpr int RPT = TU * TV / 256;
     static_assert(TU * TV % 256 == 0 && 256 % TV == 0, "tile must split into whole thread strips");
-    float *out = a.chn + (int64_t)b * a.chn_stride + L.chn_off;
+    float *out = reinterpret_cast<float *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
     const int j = tid % TV, i0 = (tid / TV) * RPT;
     const int sv = v0 + j;
     float o[RPT][4];
@@ -455,6 +473,136 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------
+// Integer channel functions of the reference's FPGA flavour (fpga/channels.py:5-67) on uint8 images:
+//   dx, dy   3x3 Sobel stencils in exact integer arithmetic; numba leaves the 1-pixel border of
+//            the (resized) image at 0 -- no reflected halo here
+//   NCH = 4  grad_hist_4_u1: y = (dx, trunc((dx-dy)/2), dy, trunc((dx+dy)/2)); min(|y| // 4, 255)
+//   NCH = 1  grad_mag_u1:    min(max(|dx|, |dy|) // 4, 255)
+// then channel_pyramid's generic tail on uint8 arrays: avg_pool_2 wraps its three uint8 adds
+// mod 256 before the /4 (channels.py:61-64), the smooth stencil sums in int64 and the /16 is
+// truncated by the store into the uint8 array (channels.py:78-90), border 0.
+// Output [u][v][NCH] uint8: one dword (NCH = 4) or one byte per pixel.
+template <int S, int TU, int TV, bool SMOOTH, int NCH>
+__global__ __launch_bounds__(256) void channels_u1_kernel(ChanArgs a) {
+    using T = uint8_t;
+    using G = TileGeom<S, TU, TV, SMOOTH>;
+    constexpr int HS = G::HS, SU = G::SU, SV = G::SV, RH = G::RH, RW = G::RW, P = G::P;
+    constexpr int UNI_BYTES = G::SH_BYTES > G::PATCH_BYTES ? G::SH_BYTES : G::PATCH_BYTES;
+    __shared__ float R[RH * RW];
+    __shared__ __attribute__((aligned(16))) unsigned char uni[UNI_BYTES];
+    uint32_t *Sh = reinterpret_cast<uint32_t *>(uni);     // packed channels of one shrunk pixel
+
+    const WbTile tile = a.tiles[blockIdx.x];
+    const WbLevel L = a.levels[tile.level];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int u0 = tile.ty * TU, v0 = tile.tx * TV;
+    const T *src = (L.oct == 0) ? (const T *)a.img + (int64_t)b * a.img_stride
+                                : (const T *)a.oct + (int64_t)b * a.oct_stride + L.src_off;
+    const uint32_t *mm = a.minmax + ((int64_t)b * a.n_oct + L.oct) * 2;
+    const double mn = Src<T>::lo(~mm[0]), mx = Src<T>::lo(mm[1]);
+    const int ry0 = S * (u0 - HS) - 1, rx0 = S * (v0 - HS) - 1;
+    resample_tile<T, G>(a, L, src, mn, mx, ry0, rx0, R, uni, tid);
+    __syncthreads();
+    if (a.dbg & 1) return;
+
+    // ---- step 2: integer gradients -> channels -> shrink, one shrunk pixel per iteration
+    for (int p = tid; p < SU * SV; p += 256) {
+        const int i = p / SV, j = p - i * SV;
+        int pt[P][P];
+#pragma unroll
+        for (int y = 0; y < P; ++y)
+#pragma unroll
+            for (int x = 0; x < P; ++x) pt[y][x] = (int)R[(S * i + y) * RW + (S * j + x)];
+        int ch[S][S][NCH];
+#pragma unroll
+        for (int y = 0; y < S; ++y)
+#pragma unroll
+            for (int x = 0; x < S; ++x) {
+                int dx = -(pt[y][x] + 2 * pt[y + 1][x] + pt[y + 2][x]) + pt[y][x + 2] + 2 * pt[y + 1][x + 2] + pt[y + 2][x + 2];
+                int dy = -(pt[y][x] + 2 * pt[y][x + 1] + pt[y][x + 2]) + pt[y + 2][x] + 2 * pt[y + 2][x + 1] + pt[y + 2][x + 2];
+                const int gy = ry0 + S * i + y + 1, gx = rx0 + S * j + x + 1;      // position in the resized image
+                if (gy <= 0 || gx <= 0 || gy >= L.nh - 1 || gx >= L.nw - 1) dx = dy = 0;
+                if constexpr (NCH == 4) {
+                    const int y4[4] = {dx, (dx - dy) / 2, dy, (dx + dy) / 2};      // C division truncates toward zero
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int v = (y4[k] < 0 ? -y4[k] : y4[k]) >> 2;
+                        ch[y][x][k] = v < 255 ? v : 255;
+                    }
+                } else {
+                    const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
+                    const int v = (ax > ay ? ax : ay) >> 2;
+                    ch[y][x][0] = v < 255 ? v : 255;
+                }
+            }
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            int v;
+            if constexpr (S == 1) {
+                v = ch[0][0][k];
+            } else if constexpr (S == 2) {
+                v = ((ch[0][0][k] + ch[1][0][k] + ch[0][1][k] + ch[1][1][k]) & 255) >> 2;
+            } else {  // S == 4 (extension): avg_pool_2 applied twice
+                int q[2][2];
+#pragma unroll
+                for (int A = 0; A < 2; ++A)
+#pragma unroll
+                    for (int B = 0; B < 2; ++B)
+                        q[A][B] = ((ch[2 * A][2 * B][k] + ch[2 * A + 1][2 * B][k] + ch[2 * A][2 * B + 1][k] +
+                                    ch[2 * A + 1][2 * B + 1][k]) & 255) >> 2;
+                v = ((q[0][0] + q[1][0] + q[0][1] + q[1][1]) & 255) >> 2;
+            }
+            o |= (uint32_t)v << (8 * k);
+        }
+        Sh[p] = o;
+    }
+    __syncthreads();
+    if (a.dbg & 2) return;
+
+    // ---- step 3: 3x3 binomial smooth, integer sum >> 4, border = 0; strips as in channels_kernel
+    constexpr int RPT = TU * TV / 256;
+    static_assert(TU * TV % 256 == 0 && 256 % TV == 0, "tile must split into whole thread strips");
+    uint8_t *out = reinterpret_cast<uint8_t *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
+    const int j = tid % TV, i0 = (tid / TV) * RPT;
+    const int sv = v0 + j;
+    uint32_t o[RPT];
+    if constexpr (SMOOTH) {
+        uint32_t w[RPT + 2][3];
+#pragma unroll
+        for (int y = 0; y < RPT + 2; ++y)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) w[y][x] = Sh[(i0 + y) * SV + (j + x)];
+#pragma unroll
+        for (int y = 0; y < RPT; ++y) {
+            o[y] = 0;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                auto at = [&](int yy, int xx) { return (int)((w[y + yy][xx] >> (8 * k)) & 255u); };
+                const int sum = at(0, 0) + 2 * at(0, 1) + at(0, 2) + 2 * at(1, 0) + 4 * at(1, 1) + 2 * at(1, 2) +
+                                at(2, 0) + 2 * at(2, 1) + at(2, 2);
+                o[y] |= (uint32_t)(sum >> 4) << (8 * k);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int y = 0; y < RPT; ++y) o[y] = Sh[(i0 + y) * SV + j];
+    }
+#pragma unroll
+    for (int y = 0; y < RPT; ++y) {
+        const int su = u0 + i0 + y;
+        if (su >= L.u || sv >= L.v || (a.dbg & 4)) continue;
+        if (SMOOTH && (su == 0 || sv == 0 || su == L.u - 1 || sv == L.v - 1)) o[y] = 0;
+        const int64_t at = (int64_t)su * L.v + sv;
+        if constexpr (NCH == 4)
+            reinterpret_cast<uint32_t *>(out)[at] = o[y];        // 64 lanes store 256 B contiguous
+        else
+            out[at] = (uint8_t)o[y];
+    }
+}
+
 // Exhaustive device check of project_int against project_f64 over [-1020, 1020]^2.
 __global__ void selftest_projection_kernel(ChanArgs a, uint32_t *mismatches) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -486,6 +634,26 @@ int launch_dtype(hipStream_t st, dim3 grid, const ChanArgs &a, int shrink, bool 
             wb_set_error("wb_channels_launch: shrink=%d unsupported (1, 2; 4 as an extension)", shrink);
             return WB_ERR_UNSUPPORTED;
     }
+    WB_HIP_CHECK(hipGetLastError());
+    return WB_OK;
+}
+
+template <int NCH>
+int launch_u1(hipStream_t st, dim3 grid, const ChanArgs &a, int shrink, bool smooth) {
+#define WB_U1(S, TU, TV)                                                                        \
+    if (smooth)                                                                                 \
+        hipLaunchKernelGGL((channels_u1_kernel<S, TU, TV, true, NCH>), grid, dim3(256), 0, st, a);  \
+    else                                                                                        \
+        hipLaunchKernelGGL((channels_u1_kernel<S, TU, TV, false, NCH>), grid, dim3(256), 0, st, a);
+    switch (shrink) {
+        case 1: WB_U1(1, 16, 64) break;
+        case 2: WB_U1(2, 16, 64) break;
+        case 4: WB_U1(4, 8, 32) break;
+        default:
+            wb_set_error("wb_channels_launch: shrink=%d unsupported (1, 2; 4 as an extension)", shrink);
+            return WB_ERR_UNSUPPORTED;
+    }
+#undef WB_U1
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;
 }
@@ -526,11 +694,23 @@ extern "C" int wb_channels_tile(int shrink, int *tile_u, int *tile_v) {
     return WB_OK;
 }
 
+extern "C" int wb_channel_func_info(int channel_func, int *n_channels, int *chn_dtype) {
+    WB_REQUIRE(n_channels && chn_dtype, "wb_channel_func_info: null pointer");
+    switch (channel_func) {
+        case WB_CHN_GRAD_HIST: *n_channels = 4; *chn_dtype = WB_DTYPE_F32; return WB_OK;
+        case WB_CHN_GRAD_HIST_4_U1: *n_channels = 4; *chn_dtype = WB_DTYPE_U8; return WB_OK;
+        case WB_CHN_GRAD_MAG_U1: *n_channels = 1; *chn_dtype = WB_DTYPE_U8; return WB_OK;
+        case WB_CHN_GRAD_MAG: *n_channels = 1; *chn_dtype = WB_DTYPE_F32; return WB_OK;
+    }
+    wb_set_error("wb_channel_func_info: unknown channel function %d", channel_func);
+    return WB_ERR_INVALID;
+}
+
 extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_stride, const void *oct,
                                   int64_t oct_stride, int dtype, int batch, const WbLevel *levels,
                                   int n_levels, const WbTile *tiles, int n_tiles, const uint32_t *minmax,
-                                  int n_oct, const WbTap *taps, int shrink, int smooth, const double *cs_sn,
-                                  float *chn, int64_t chn_stride) {
+                                  int n_oct, const WbTap *taps, int channel_func, int shrink, int smooth,
+                                  const double *cs_sn, void *chn, int64_t chn_stride) {
     WB_REQUIRE(img && levels && tiles && minmax && taps && cs_sn && chn, "wb_channels_launch: null pointer");
     WB_REQUIRE(batch >= 1 && n_levels >= 1 && n_tiles >= 1, "wb_channels_launch: empty launch");
     WB_REQUIRE(batch <= 65535, "wb_channels_launch: batch %d exceeds grid.y limit", batch);
@@ -553,6 +733,18 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
     a.dbg = dbg;
     dim3 grid((unsigned)n_tiles, (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;
+    if (channel_func == WB_CHN_GRAD_HIST_4_U1 || channel_func == WB_CHN_GRAD_MAG_U1) {
+        if (dtype != WB_DTYPE_U8) {
+            wb_set_error("wb_channels_launch: the uint8 channel functions take uint8 images (8 bit input, fpga/channels.py:32)");
+            return WB_ERR_UNSUPPORTED;
+        }
+        return channel_func == WB_CHN_GRAD_HIST_4_U1 ? launch_u1<4>(st, grid, a, shrink, smooth != 0)
+                                                     : launch_u1<1>(st, grid, a, shrink, smooth != 0);
+    }
+    if (channel_func != WB_CHN_GRAD_HIST) {
+        wb_set_error("wb_channels_launch: channel function %d has no kernel", channel_func);
+        return WB_ERR_UNSUPPORTED;
+    }
     if (dtype == WB_DTYPE_U8) {
         // integer gradients + canonical constants: exact fp32 projection (see project_int)
         static const bool no_fast = getenv("WB_CHAN_NO_FAST") != nullptr;

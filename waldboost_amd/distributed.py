@@ -80,9 +80,9 @@ def detect_sharded(model, images, group=None):
     lo, hi = shard_range(B, rank, world)
     counts = [shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world)]
     nb = max(counts)                                   # every rank runs the same (padded) batch size
-    shrink, n_per_oct, smooth = _channels.read_opts(model.channel_opts)
+    shrink, n_per_oct, smooth, spec = _channels.read_opts(model.channel_opts)
     H, W = int(images.shape[1]), int(images.shape[2])
-    eng = _engine.get_engine(H, W, images.dtype, shrink, n_per_oct, smooth, nb)
+    eng = _engine.get_engine(H, W, images.dtype, shrink, n_per_oct, smooth, nb, channels=spec)
     local = np.zeros((nb, H, W), images.dtype)
     local[: hi - lo] = images[lo:hi]
     dm = model.device_cascade()

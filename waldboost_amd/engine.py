@@ -13,6 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as nat
+from .chanfunc import SPECS
 from .plan import PyramidPlan, N_CHANNELS
 
 _TORCH_DT = {}
@@ -135,15 +136,20 @@ def sort_records(d):
 
 
 class PyramidEngine:
-    def __init__(self, H, W, dtype, shrink, n_per_oct, smooth, batch=1, exact_single=False, det_capacity=1 << 16):
+    def __init__(self, H, W, dtype, shrink, n_per_oct, smooth, batch=1, exact_single=False, det_capacity=1 << 16,
+                 channels=None):
         import torch
         self.lib = nat.load()
         self.dev = nat.require_gpu()
         self.dtype = np.dtype(dtype)
+        self.spec = channels if channels is not None else SPECS["grad_hist"]
+        if self.spec.dtype == np.uint8 and self.dtype != np.uint8:
+            raise NotImplementedError(f"{self.spec.key} takes 8 bit images (uint8), got {self.dtype}")
         self.tdtype = _torch_dtype(dtype)
         self.wb_dtype = nat.WB_DTYPE_U8 if self.dtype == np.uint8 else nat.WB_DTYPE_F32
         self.batch = int(batch)
-        self.plan = PyramidPlan(H, W, shrink, n_per_oct, smooth, exact_single=exact_single)
+        self.plan = PyramidPlan(H, W, shrink, n_per_oct, smooth, exact_single=exact_single,
+                                n_chn=self.spec.n_channels, chn_bytes=self.spec.dtype.itemsize)
         self.exact_single = exact_single
         p = self.plan
         dev = self.dev
@@ -163,7 +169,7 @@ class PyramidEngine:
         tiles = p.chan_tiles()
         self.n_chan_tiles = int(tiles.size)
         self.chan_tiles = torch.from_numpy(tiles.view(np.uint8).copy()).to(dev) if tiles.size else None
-        self.chn = torch.zeros((self.batch, self.chn_stride), dtype=torch.float32, device=dev)
+        self.chn = torch.zeros((self.batch, self.chn_stride), dtype=_torch_dtype(self.spec.dtype), device=dev)
         self.cs_sn = orientation_constants()
         self._oct_off = (C.c_int64 * max(p.n_oct, 1))(*[int(x) for x in p.oct_off[:max(p.n_oct, 1)]])
         self.det_capacity = int(det_capacity)
@@ -220,7 +226,8 @@ class PyramidEngine:
         nat.check(self.lib.wb_channels_launch(nat.stream_ptr(), nat.ptr(self.img), p.H * p.W, nat.ptr(self.oct),
                                               p.oct_total, self.wb_dtype, self.batch, nat.ptr(self.levels),
                                               p.n_levels, nat.ptr(self.chan_tiles), self.n_chan_tiles,
-                                              nat.ptr(self.minmax), max(p.n_oct, 1), nat.ptr(self.taps), p.shrink, p.smooth,
+                                              nat.ptr(self.minmax), max(p.n_oct, 1), nat.ptr(self.taps),
+                                              self.spec.func_id, p.shrink, p.smooth,
                                               self.cs_sn.ctypes.data_as(C.POINTER(C.c_double)), nat.ptr(self.chn),
                                               self.chn_stride), "wb_channels_launch")
 
@@ -249,7 +256,8 @@ class PyramidEngine:
         stt = self._casc_state(dm)
         if stt["n_tiles"] == 0:
             return stt
-        nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.chn), self.chn_stride,
+        nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.chn), self.spec.wb_dtype,
+                                             self.chn_stride,
                                              self.batch, nat.ptr(self.levels), self.plan.n_levels,
                                              nat.ptr(stt["tiles"]), nat.ptr(stt["csr"]), stt["n_tiles"],
                                              nat.ptr(self.detb.recs), nat.ptr(self.detb.counts), self.detb.cap,
@@ -315,11 +323,11 @@ class PyramidEngine:
         return boxes, scores
 
     def read_level(self, b, l):
-        """Channels of level l of image b as a fresh HWC float32 ndarray [u,v,4]."""
+        """Channels of level l of image b as a fresh HWC ndarray [u,v,C] of the channel function's dtype."""
         lv = self.plan.levels[l]
         off = int(self.level_np[l]["chn_off"])
-        u, v = lv["u"], lv["v"]
-        return self.chn[b, off:off + u * v * N_CHANNELS].reshape(u, v, N_CHANNELS).cpu().numpy()
+        u, v, C = lv["u"], lv["v"], self.spec.n_channels
+        return self.chn[b, off:off + u * v * C].reshape(u, v, C).cpu().numpy()
 
 
 def nat_f32_key(f):
@@ -330,15 +338,16 @@ def nat_f32_key(f):
 _ENGINES = {}
 
 
-def get_engine(H, W, dtype, shrink, n_per_oct, smooth, batch=1, exact_single=False):
+def get_engine(H, W, dtype, shrink, n_per_oct, smooth, batch=1, exact_single=False, channels=None):
     """Small cache of engines keyed by configuration (buffers are reused across calls)."""
     import torch
+    channels = channels if channels is not None else SPECS["grad_hist"]
     key = (int(H), int(W), np.dtype(dtype).str, int(shrink), int(n_per_oct), int(smooth), int(batch),
-           bool(exact_single), torch.cuda.current_device() if torch.cuda.is_available() else -1)
+           bool(exact_single), channels.key, torch.cuda.current_device() if torch.cuda.is_available() else -1)
     e = _ENGINES.get(key)
     if e is None:
         if len(_ENGINES) >= 4:
             _ENGINES.pop(next(iter(_ENGINES)))
-        e = PyramidEngine(H, W, dtype, shrink, n_per_oct, smooth, batch, exact_single)
+        e = PyramidEngine(H, W, dtype, shrink, n_per_oct, smooth, batch, exact_single, channels=channels)
         _ENGINES[key] = e
     return e

@@ -16,13 +16,12 @@ from .boxes import Boxes, concatenate
 from .channels import channel_pyramid
 from .training import DTree
 
-# the name written into .pb files for our grad_hist, so that the reference can load them too
-_REFERENCE_NAME = "waldboost.channels.grad_hist"
-
-
 def symbol_name(s):
-    if _channels.is_grad_hist(s):
-        return _REFERENCE_NAME
+    """Name written into .pb files: the reference's own module.qualname for the channel functions
+    this build implements, so that the reference can load our files too (model.py:23-24, 302)."""
+    spec = _channels.channel_spec(s)
+    if spec is not None:
+        return spec.reference_name
     return s.__module__ + "." + s.__qualname__
 
 
@@ -114,9 +113,9 @@ class Model:
         u, v, ch_image = X.shape
         m, n, ch_cls = self.shape
         assert ch_image == ch_cls, f"Invalid number of channels. Expected {ch_cls} given {ch_image}."
-        _require_float32(X)
+        xdt = _channel_dtype(X)
         dm = self.device_cascade()
-        eng = _SingleLevel.get(u, v, ch_image)
+        eng = _SingleLevel.get(u, v, ch_image, xdt)
         eng.load(X)
         n_det, alive = eng.scan(dm)
         self.n_loc += max(u - m, 0) * max(v - n, 0)
@@ -140,12 +139,12 @@ class Model:
         """detect() with everything the parity tests compare: boxes, scores, (level, r, c),
         alive[level, stage]; updates n_loc / n_weak."""
         _channels._validate_image(image)
-        shrink, n_per_oct, smooth = _channels.read_opts(self.channel_opts)
+        shrink, n_per_oct, smooth, spec = _channels.read_opts(self.channel_opts)
         m, n, Cc = self.shape
-        assert Cc == 4, f"Invalid number of channels. Expected {Cc} given 4."
+        assert Cc == spec.n_channels, f"Invalid number of channels. Expected {Cc} given {spec.n_channels}."
         H, W = image.shape
         dm = self.device_cascade()
-        eng = _engine.get_engine(H, W, image.dtype, shrink, n_per_oct, smooth, 1)
+        eng = _engine.get_engine(H, W, image.dtype, shrink, n_per_oct, smooth, 1, channels=spec)
         T = len(self)
         if eng.plan.n_levels == 0:
             return dict(boxes=np.empty((0, 4), "f"), scores=np.empty(0, "f"), level=np.empty(0, np.int32),
@@ -160,7 +159,7 @@ class Model:
         by the caller: several models can share one pyramid, reference __init__.py:120-124).
         Returns the same dict as detect_raw and updates n_loc / n_weak."""
         m, n, Cc = self.shape
-        assert Cc == 4, f"Invalid number of channels. Expected {Cc} given 4."
+        assert Cc == eng.spec.n_channels, f"Invalid number of channels. Expected {Cc} given {eng.spec.n_channels}."
         dm = self.device_cascade()
         T = len(self)
         stt = eng.run_cascade(dm)
@@ -195,12 +194,12 @@ class Model:
         dtype = images.dtype if isinstance(images, np.ndarray) else {"torch.uint8": np.uint8, "torch.float32": np.float32}.get(str(images.dtype))
         if dtype is None:
             raise NotImplementedError(f"image dtype {images.dtype} has no HIP kernel (uint8 and float32 are supported)")
-        shrink, n_per_oct, smooth = _channels.read_opts(self.channel_opts)
+        shrink, n_per_oct, smooth, spec = _channels.read_opts(self.channel_opts)
         m, n, Cc = self.shape
-        assert Cc == 4, f"Invalid number of channels. Expected {Cc} given 4."
+        assert Cc == spec.n_channels, f"Invalid number of channels. Expected {Cc} given {spec.n_channels}."
         dm = self.device_cascade()
         T = len(self)
-        eng = _engine.get_engine(H, W, dtype, shrink, n_per_oct, smooth, B)
+        eng = _engine.get_engine(H, W, dtype, shrink, n_per_oct, smooth, B, channels=spec)
         L = eng.plan.n_levels
         if L == 0:
             return dict(batch=B, image=np.empty(0, np.int32), level=np.empty(0, np.int32), r=np.empty(0, np.int64),
@@ -269,12 +268,14 @@ class Model:
         return Model.from_proto(proto)
 
 
-def _require_float32(X):
-    """Channel images are float32 (what channel_pyramid yields).  The reference would compare a
-    float64 X with its float32 thresholds in float64; silently casting X would change results."""
-    dt = getattr(X, "dtype", None)
-    if str(dt).replace("torch.", "") != "float32":
-        raise TypeError(f"channel image must be float32 (as produced by channel_pyramid), got {dt}")
+def _channel_dtype(X):
+    """Channel images are float32 or uint8 (what channel_pyramid yields; a uint8 value compares
+    against the float32 thresholds as its exact float32 value, like NumPy's promotion).  The
+    reference would compare a float64 X in float64; silently casting X would change results."""
+    dt = str(getattr(X, "dtype", None)).replace("torch.", "")
+    if dt not in ("float32", "uint8"):
+        raise TypeError(f"channel image must be float32 or uint8 (as produced by channel_pyramid), got {dt}")
+    return np.dtype(dt)
 
 
 class _SingleLevel:
@@ -282,17 +283,18 @@ class _SingleLevel:
     _cache = {}
 
     @classmethod
-    def get(cls, u, v, C):
+    def get(cls, u, v, C, dtype=np.float32):
         import torch
-        key = (u, v, C, torch.cuda.current_device() if torch.cuda.is_available() else -1)
+        dtype = np.dtype(dtype)
+        key = (u, v, C, dtype.str, torch.cuda.current_device() if torch.cuda.is_available() else -1)
         e = cls._cache.get(key)
         if e is None:
             if len(cls._cache) >= 8:
                 cls._cache.pop(next(iter(cls._cache)))
-            e = cls._cache[key] = cls(u, v, C)
+            e = cls._cache[key] = cls(u, v, C, dtype)
         return e
 
-    def __init__(self, u, v, C):
+    def __init__(self, u, v, C, dtype=np.float32):
         import torch
         self.lib = nat.load()
         self.dev = nat.require_gpu()
@@ -302,16 +304,19 @@ class _SingleLevel:
         t = np.zeros(1, nat.LEVEL_DTYPE)
         t[0]["u"], t[0]["v"], t[0]["chn_off"] = u, v, 0
         self.levels = torch.from_numpy(t.view(np.uint8).copy()).to(self.dev)
-        self.X = torch.empty((max(u * v * C, 1),), dtype=torch.float32, device=self.dev)
+        self.dtype = np.dtype(dtype)
+        self.tdtype = torch.uint8 if self.dtype == np.uint8 else torch.float32
+        self.wb_dtype = nat.WB_DTYPE_U8 if self.dtype == np.uint8 else nat.WB_DTYPE_F32
+        self.X = torch.empty((max(u * v * C, 1) + 4,), dtype=self.tdtype, device=self.dev)
         self.detb = _engine.DetBuffer(1 << 10, self.dev)
         self._tiles = {}
 
     def load(self, X):
         import torch
         if isinstance(X, torch.Tensor):
-            self.X[:self.u * self.v * self.C].copy_(X.to(torch.float32).reshape(-1))
+            self.X[:self.u * self.v * self.C].copy_(X.to(self.tdtype).reshape(-1))
         else:
-            self.X[:self.u * self.v * self.C].copy_(torch.from_numpy(np.ascontiguousarray(X, np.float32).reshape(-1)))
+            self.X[:self.u * self.v * self.C].copy_(torch.from_numpy(np.ascontiguousarray(X, self.dtype).reshape(-1)))
 
     def scan(self, dm):
         import torch
@@ -329,7 +334,7 @@ class _SingleLevel:
         while True:
             self.detb.zero()
             if n_tiles:
-                nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.X), 0,
+                nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.X), self.wb_dtype, 0,
                                                      1, nat.ptr(self.levels), 1, nat.ptr(tiles), nat.ptr(csr), n_tiles,
                                                      nat.ptr(self.detb.recs), nat.ptr(self.detb.counts), self.detb.cap,
                                                      nat.ptr(tile_hist), nat.ptr(alive)), "wb_cascade_launch")

@@ -8,7 +8,9 @@ HBM layout per image (one contiguous buffer each, images of a batch at a fixed s
   octaves   : octave k>=1 at element offset oct_off[k] (octave 0 is the image itself)
   channels  : level l at float offset chn_off[l], [u][v][4]: one aligned float4 per pixel -- the
               layout channel_pyramid hands to callers, 16-byte stores for the channel kernel and
-              one contiguous run per tile row for the cascade
+              one contiguous run per tile row for the cascade.  Other channel functions give
+              [u][v][C] in their own dtype (uint8 x4 = one dword per pixel, or one channel);
+              offsets count elements and every level starts on a multiple of 4 elements
 """
 import math
 
@@ -16,7 +18,7 @@ import numpy as np
 
 from ._native import LEVEL_DTYPE, TAP_DTYPE, TILE_DTYPE
 
-N_CHANNELS = 4          # grad_hist with n_bins=4 (reference channels.py:40)
+N_CHANNELS = 4          # grad_hist with n_bins=4 (reference channels.py:40): the default channel function
 CHAN_TILES = {1: (16, 64), 2: (16, 64), 4: (8, 32)}   # must match wb_channels_tile()
 
 
@@ -41,10 +43,11 @@ def xcd_order(n):
 
 
 class PyramidPlan:
-    def __init__(self, H, W, shrink, n_per_oct, smooth=1, exact_single=False):
+    def __init__(self, H, W, shrink, n_per_oct, smooth=1, exact_single=False, n_chn=N_CHANNELS, chn_bytes=4):
         assert shrink in (1, 2, 4), "Shrink factor must be 1 or 2 (4 is a documented extension)"
         self.H, self.W = int(H), int(W)
         self.shrink, self.n_per_oct, self.smooth = int(shrink), int(n_per_oct), int(smooth)
+        self.n_chn, self.chn_bytes = int(n_chn), int(chn_bytes)     # channels per pixel, bytes per channel value
         self.octaves = octave_shapes(H, W)
         self.n_oct = len(self.octaves)
         off, acc = [], 0
@@ -85,7 +88,7 @@ class PyramidPlan:
         offs, acc = [], 0
         for lv in self.levels:
             offs.append(acc)
-            acc += N_CHANNELS * lv["u"] * lv["v"]
+            acc += (self.n_chn * lv["u"] * lv["v"] + 3) & ~3
         return offs, max(acc, 4)
 
     @staticmethod
@@ -185,10 +188,11 @@ class PyramidPlan:
     # ------------------------------------------------------------------ roofline arithmetic
     def algorithmic_bytes(self, px_bytes):
         """Per image, SURVEY section 8(d): image read + octave writes + per-level source reads
-        + channel write (+ the same bytes again for the cascade's read)."""
+        + channel write (+ the same bytes again for the cascade's read); channels in the dtype
+        and count of the plan's channel function."""
         img = self.H * self.W * px_bytes
         octw = sum(h * w for h, w in self.octaves[1:]) * px_bytes
         src = sum(lv["h"] * lv["w"] for lv in self.levels) * px_bytes
-        chn = sum(lv["u"] * lv["v"] for lv in self.levels) * N_CHANNELS * 4
+        chn = sum(lv["u"] * lv["v"] for lv in self.levels) * self.n_chn * self.chn_bytes
         return dict(image=img, octaves=octw, level_src=src, chn_write=chn, chn_read=chn,
                     channels_kernel=src + chn, cascade_kernel=chn, total=img + octw + src + 2 * chn)

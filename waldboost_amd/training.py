@@ -68,18 +68,21 @@ class DTree:
         if rs.size == 0:
             return np.empty(0, np.float32)
         u, v, C = X.shape
-        if str(getattr(X, "dtype", None)).replace("torch.", "") != "float32":
-            raise TypeError(f"channel image must be float32 (as produced by channel_pyramid), got {getattr(X, 'dtype', None)}")
+        xdt = str(getattr(X, "dtype", None)).replace("torch.", "")
+        if xdt not in ("float32", "uint8"):
+            raise TypeError(f"channel image must be float32 or uint8 (as produced by channel_pyramid), got {xdt}")
+        np_dt, t_dt = (np.uint8, torch.uint8) if xdt == "uint8" else (np.float32, torch.float32)
+        wb_dt = nat.WB_DTYPE_U8 if xdt == "uint8" else nat.WB_DTYPE_F32
         fmax = self.feature[self.node].max(axis=0) if self.node.any() else np.zeros(3, np.int64)
         if rs.min() < 0 or cs.min() < 0 or rs.max() + int(fmax[0]) >= u or cs.max() + int(fmax[1]) >= v or int(fmax[2]) >= C:
             raise IndexError("window feature outside the channel image")
-        Xd = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X, np.float32))
-        Xd = Xd.to(dev, torch.float32).contiguous()
+        Xd = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X, np_dt))
+        Xd = Xd.to(dev, t_dt).contiguous()
         rd = torch.from_numpy(rs.astype(np.int32)).to(dev)
         cd = torch.from_numpy(cs.astype(np.int32)).to(dev)
         out = torch.empty(rs.size, dtype=torch.float32, device=dev)
         f, t, l, r, p = self._device_arrays(dev)
-        nat.check(lib.wb_tree_eval_launch(nat.stream_ptr(), nat.ptr(Xd), u, v, C, nat.ptr(rd), nat.ptr(cd), rs.size,
+        nat.check(lib.wb_tree_eval_launch(nat.stream_ptr(), nat.ptr(Xd), wb_dt, u, v, C, nat.ptr(rd), nat.ptr(cd), rs.size,
                                           nat.ptr(f), nat.ptr(t), nat.ptr(l), nat.ptr(r), nat.ptr(p),
                                           self.left.size, nat.ptr(out)), "wb_tree_eval_launch")
         return out.cpu().numpy()
