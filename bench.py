@@ -30,30 +30,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-MODEL = os.path.join(ROOT, "tests", "golden", "models", "cfg2_d2_T128.pb")
+MODELS = {"grad_hist": os.path.join(ROOT, "tests", "golden", "models", "cfg2_d2_T128.pb"),
+          # secondary workload: the reference's integer channels, uint8 x4 per pixel
+          "grad_hist_4_u1": os.path.join(ROOT, "tests", "golden", "models", "cfg2_gh4u1_d2_T128.pb")}
+MODEL = MODELS["grad_hist"]
 H, W = 1080, 1920
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
 # ----------------------------------------------------------------------------- CPU baseline
-def _cpu_worker(seed):
+def _cpu_worker(job):
+    seed, model_path = job
     import waldboost_amd as wb          # host-side .pb reader only; no GPU is touched here
     from util import oracle_detect
     from waldboost_amd.synth import synth_image
-    M = wb.load(MODEL)
+    M = wb.load(model_path)
     t0 = time.perf_counter()
     res = oracle_detect(M, synth_image(H, W, seed))
     return res["n_loc"], time.perf_counter() - t0
 
 
-def cpu_baseline(images_per_core=6, max_cores=16):
+def cpu_baseline(model_path, images_per_core=6, max_cores=16):
     import multiprocessing as mp
     cores = max(1, min(max_cores, os.cpu_count() or 1))
     n = cores * images_per_core
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
-        out = pool.map(_cpu_worker, range(n))
+        out = pool.map(_cpu_worker, [(i, model_path) for i in range(n)])
     wall = time.perf_counter() - t0
     windows = sum(o[0] for o in out)
     return {"value": windows / wall, "unit": "windows/s", "cores": cores, "kind": "port",
@@ -86,6 +90,9 @@ def main():
                     help="HIP streams the steps are spread over (<= pool): consecutive steps work on different "
                          "images, so their kernels may overlap on the GPU like frames of a video pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--channels", choices=sorted(MODELS), default="grad_hist",
+                    help="channel function of the workload; grad_hist is the BASELINE config, grad_hist_4_u1 the "
+                         "reference's integer channels (same geometry, uint8 channels, its own calibrated cascade)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                                                       "rehearse the multi-rank loop with several ranks on one GPU)")
     ap.add_argument("--stages", type=int, default=0, help="diagnostic: keep only the first N stages of the cascade")
@@ -102,7 +109,7 @@ def main():
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline and args.only == "all":
-        cpu = cpu_baseline()            # before the GPU is initialised (fork-safe)
+        cpu = cpu_baseline(MODELS[args.channels])            # before the GPU is initialised (fork-safe)
 
     import torch
     import torch.distributed as dist
@@ -120,14 +127,15 @@ def main():
     from waldboost_amd.synth import synth_image
     from waldboost_amd.distributed import DetectionGatherer
 
-    M = wb.load(MODEL)
+    M = wb.load(MODELS[args.channels])
+    spec = wb.channels.channel_spec(M.channel_opts["channels"])
     if args.stages:
         M.classifier, M.theta = M.classifier[:args.stages], M.theta[:args.stages]
     dm = M.device_cascade()
     B, P = args.batch, max(1, args.pool)
     engines = []
     for i in range(P):
-        e = PyramidEngine(H, W, np.uint8, 2, 8, 1, batch=B, det_capacity=16384 * B)
+        e = PyramidEngine(H, W, np.uint8, 2, 8, 1, batch=B, det_capacity=16384 * B, channels=spec)
         seeds = [(rank * P + i) * B + b for b in range(B)]
         e.load_images(np.stack([synth_image(H, W, s) for s in seeds]))
         engines.append(e)
@@ -239,7 +247,7 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 PMC passes (batch-1 launches only)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01", "traffic_pmc.json")
-        if os.path.exists(tpath) and B == 1:
+        if os.path.exists(tpath) and B == 1 and args.channels == "grad_hist":
             with open(tpath) as f:
                 tj = json.load(f)
             key = "channels_kernel" if name == "channels_kernel" else "cascade_tile_kernel"
@@ -252,11 +260,14 @@ def main():
         windows = world * args.steps * B * n_loc
         ab = plan.algorithmic_bytes(1)
         out = {
-            "metric": "candidate windows/s, 1080p grad_hist pyramid, 128-stage depth-2 cascade",
+            "metric": f"candidate windows/s, 1080p {args.channels} pyramid, 128-stage depth-2 cascade",
             "value": windows / dt, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8 image, f64/f32 channel arithmetic, f32 scores", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: 1920x1080 uint8, shrink=2 n_per_oct=8 smooth=1 grad_hist, "
+            "vs_baseline": None,
+            "dtype": "u8 image, f64/f32 channel arithmetic, f32 scores" if args.channels == "grad_hist"
+                     else "u8 image, integer channel arithmetic (u8 channels), f32 scores",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: 1920x1080 uint8, shrink=2 n_per_oct=8 smooth=1 {args.channels}, "
                                    f"window (12,12,4), 128-stage depth-2 cascade, {B} image(s)/step/GPU",
                        "batch_per_gpu": B, "levels": plan.n_levels, "windows_per_image": n_loc,
                        "launch": "eager" if args.no_graph else "hipGraph replay", "only": args.only,

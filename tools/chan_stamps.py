@@ -1,0 +1,26 @@
+"""Diagnostic (STAMPS=1 build of csrc only): mean wall-clock per phase of the channel kernel."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from waldboost_amd import _native as nat
+from waldboost_amd.engine import PyramidEngine
+from waldboost_amd.synth import synth_image
+lib = nat.load()
+lib.wb_debug_channel_stamps.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+e = PyramidEngine(1080, 1920, np.uint8, 2, 8, 1, batch=B)
+e.load_images(np.stack([synth_image(1080, 1920, s) for s in range(B)]))
+e.run_channels(); torch.cuda.synchronize()
+for _ in range(3):
+    e.launch_channels()
+torch.cuda.synchronize()
+n_wg = min(e.n_chan_tiles * B, 1 << 17)
+out = (C.c_double * 7)(); life = C.c_double()
+lib.wb_debug_channel_stamps(n_wg, out, C.byref(life))
+names = ["tile/level/extent loads", "stage source patch + barrier", "row loop (resample)", "leftover columns + barrier",
+         "step 2 (gradients, projection, shrink) + barrier", "step 3 (smooth)", "stores"]
+print(f"B={B}: {n_wg} workgroups, mean lifetime {life.value:.2f} us")
+for n, v in zip(names, out):
+    print(f"  {n:50s} {v:6.2f} us")

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwaldboost_hip.so")
+# WB_NATIVE_LIB: A/B timing of two builds of the same ABI in one session (diagnostic)
+LIB_PATH = os.environ.get("WB_NATIVE_LIB") or os.path.join(_HERE, "csrc", "libwaldboost_hip.so")
 
 WB_DTYPE_U8, WB_DTYPE_F32 = 0, 1
 WB_ERR_INVALID, WB_ERR_HIP, WB_ERR_UNSUPPORTED = -1, -2, -3

@@ -145,7 +145,7 @@ __device__ inline int lane_rank(unsigned long long mask) {
 // at any stage < T.
 template <int D> struct GroupSize { static constexpr int G = (D >= 3) ? 2 : 4; };
 
-template <int D, int RPW, int WAVES>
+template <int D, int RPW, int WAVES, bool U8>
 __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, const int32_t *__restrict__ stages) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t wcnt[WAVES];
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     const float *chn = reinterpret_cast<const float *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
     const uint8_t *chn8 = reinterpret_cast<const uint8_t *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
     if (a.dbg & 1) {
-    } else if (a.chn_u8 && a.C == 4) {
+    } else if (U8 && a.C == 4) {
         // uint8 channels, one dword per pixel: same batched scheme as the float4 path below; the
         // four bytes are widened to their exact float32 values on the way into the LDS planes
         // (uint8 <= float32 compares in float32 under NumPy promotion), so the stage loop is unchanged
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
             float v = 0.f;
             if (gr < L.u && gc < L.v) {
                 const int64_t at = ((int64_t)gr * L.v + gc) * a.C + ch;
-                v = a.chn_u8 ? (float)chn8[at] : chn[at];
+                v = U8 ? (float)chn8[at] : chn[at];
             }
             tile[(ch * rows + row) * pitch + col] = v;
         }
@@ -659,7 +659,10 @@ template <int D>
 int launch_depth(hipStream_t st, dim3 grid, const CascArgs &a, int rpw, int waves, size_t lds) {
 #define WB_X(R, W)                                                                                          \
     if (rpw == R && waves == W) {                                                                           \
-        hipLaunchKernelGGL((cascade_tile_kernel<D, R, W>), grid, dim3(W * 64), lds, st, a, a.stages);       \
+        if (a.chn_u8)                                                                                       \
+            hipLaunchKernelGGL((cascade_tile_kernel<D, R, W, true>), grid, dim3(W * 64), lds, st, a, a.stages);  \
+        else                                                                                                \
+            hipLaunchKernelGGL((cascade_tile_kernel<D, R, W, false>), grid, dim3(W * 64), lds, st, a, a.stages); \
         if (a.T > 0)                                                                                        \
             hipLaunchKernelGGL(alive_reduce_kernel, dim3(a.n_levels, grid.y), dim3(1024),                          \
                                0, st, a.tile_hist, a.tile_csr, a.n_levels, a.n_tiles, a.T, a.alive);         \
@@ -676,7 +679,9 @@ template <int D>
 int prepare_depth(int rpw, int waves) {
 #define WB_X(R, W)                                                                                          \
     if (rpw == R && waves == W) {                                                                           \
-        WB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&cascade_tile_kernel<D, R, W>),     \
+        WB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&cascade_tile_kernel<D, R, W, false>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));          \
+        WB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&cascade_tile_kernel<D, R, W, true>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));          \
         return WB_OK;                                                                                       \
     }

@@ -31,8 +31,26 @@ struct ChanArgs {
     int64_t chn_stride;
     double cs[4], sn[4];
     float chi, clo;      // sin(pi/4) = chi + clo (two-float split) for the integer-gradient fast path
+    float c2hi, c2lo;    // cos(pi/2) (fp64: 6.1e-17) likewise
     int dbg;             // diagnostics (WB_CHAN_DBG): 1 = stop after step 1, 2 = after step 2, 4 = skip the stores
 };
+
+// Diagnostic build only (make STAMPS=1): thread 0 of every workgroup stores s_memrealtime at the
+// phase boundaries into a private slot; wb_debug_channel_stamps turns them into mean wall-clock per
+// phase.  Never part of a measured build.
+#ifdef WB_CASC_STAMPS
+#define WB_CSTAMP_SLOTS 8
+#define WB_CSTAMP_WGS (1 << 17)
+__device__ unsigned long long g_chan_stamps[WB_CSTAMP_WGS * WB_CSTAMP_SLOTS];
+#define WB_CSTAMP(k)                                                                                      \
+    do {                                                                                                  \
+        unsigned long long _wg = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;                 \
+        if (threadIdx.x == 0 && _wg < WB_CSTAMP_WGS)                                                      \
+            g_chan_stamps[_wg * WB_CSTAMP_SLOTS + (k)] = __builtin_amdgcn_s_memrealtime();                \
+    } while (0)
+#else
+#define WB_CSTAMP(k) do {} while (0)
+#endif
 
 typedef WbTap Tap;   // one axis of the bilinear resample (scipy NI_ZoomShift, order 1), host-built table
 
@@ -53,13 +71,15 @@ template <> struct Src<uint8_t> {
     // fp64 value within 1e-12: unless the estimate lies within EPS of an integer both have the same
     // floor.  Lanes inside that band (flat 2x2 patches always are) redo the pixel in fp64.
     static constexpr float kEps = 2.5e-4f;
+    // No clip here: outside the band the exact value lies strictly between two integers of
+    // [min, max] (it is a convex combination of pixels of the octave), so its floor is in range.
     static __device__ bool fast(float v00, float v01, float v10, float v11, float wr0, float wr1, float wc0, float wc1,
-                                float mn, float mx, float &out) {
+                                float &out) {
         float top = __builtin_fmaf(v01, wc1, v00 * wc0), bot = __builtin_fmaf(v11, wc1, v10 * wc0);
         float t = __builtin_fmaf(bot, wr1, top * wr0);
         float fl = floorf(t), fr = t - fl;
-        out = fminf(fmaxf(fl, mn), mx);
-        return !(fr < kEps || fr > 1.0f - kEps);
+        out = fl;
+        return fabsf(fr - 0.5f) <= 0.5f - kEps;
     }
     static __device__ double lo(uint32_t k) { return (double)k; }
     // fp64 result is clipped in fp64, then cast to uint8 by truncation
@@ -73,7 +93,7 @@ template <> struct Src<uint8_t> {
 };
 template <> struct Src<float> {
     static constexpr bool kFastResample = false;
-    static __device__ bool fast(float, float, float, float, float, float, float, float, float, float, float &) { return false; }
+    static __device__ bool fast(float, float, float, float, float, float, float, float, float &) { return false; }
     static __device__ double lo(uint32_t k) { return (double)wb_key_f32(k); }
     // float32 images: zoom stores fp32, then np.clip in fp32
     static __device__ float finish(double t, double mn, double mx) {
@@ -119,19 +139,23 @@ __device__ inline void project_f64(float gx, float gy, const ChanArgs &a, float 
 
 // Integer-valued gradients (uint8 images: |g| <= 1020) with the canonical 4-bin constants:
 // bit-identical to project_f64 for every (gx, gy) in [-1020, 1020]^2 -- checked exhaustively on
-// the device by wb_selftest_projection -- because
-//   k=0: gx*1 - gy*0 = gx;            k=2: gx*6.1e-17 - gy rounds to -gy unless gy == 0;
-//   k=1,3: the result depends only on d = |gx -/+ gy| (the 1-ulp difference between cos and sin
-//          of pi/4 is far below fp32 resolution unless d == 0) and fp32(d * sin(pi/4)) equals
-//          fma(d, chi, d*clo) for all d <= 2040.
-// The excluded lanes (gx != 0 and one of gy, gx-gy, gx+gy zero) take the fp64 path.
+// the device by wb_selftest_projection -- and branch-free:
+//   k=0: gx*1 - gy*0 = gx
+//   k=2: gx*6.1e-17 - gy rounds to -gy unless gy == 0; then it is fp32(gx * cos(pi/2)), which a
+//        two-float split of the constant reproduces
+//   k=1,3: the result depends only on d = |gx -/+ gy| (the 1-ulp difference between the fp64 cos
+//        and sin of pi/4 is far below fp32 resolution) and fp32(d * sin(pi/4)) equals
+//        fma(d, chi, d*clo) for all d <= 2040 -- unless d == 0: then what is left is that 1-ulp
+//        difference, |RN64(gx*c1) - RN64(gx*s1)| (0 or one ulp of the product), computed as such.
 __device__ inline void project_int(float gx, float gy, const ChanArgs &a, float *out) {
-    float d1 = fabsf(gx - gy), d3 = fabsf(gx + gy);
-    out[0] = fabsf(gx);
-    out[1] = __builtin_fmaf(d1, a.chi, d1 * a.clo);
-    out[2] = fabsf(gy);
-    out[3] = __builtin_fmaf(d3, a.chi, d3 * a.clo);
-    if (gx != 0.0f && (gy == 0.0f || d1 == 0.0f || d3 == 0.0f)) project_f64(gx, gy, a, out);
+    const float d1 = fabsf(gx - gy), d3 = fabsf(gx + gy), ax = fabsf(gx);
+    const double g = (double)gx;
+    const float tiny = fabsf((float)(g * a.cs[1] - g * a.sn[1]));
+    const float o1 = __builtin_fmaf(d1, a.chi, d1 * a.clo), o3 = __builtin_fmaf(d3, a.chi, d3 * a.clo);
+    out[0] = ax;
+    out[1] = d1 == 0.0f ? tiny : o1;
+    out[2] = gy == 0.0f ? __builtin_fmaf(ax, a.c2hi, ax * a.c2lo) : fabsf(gy);
+    out[3] = d3 == 0.0f ? tiny : o3;
 }
 
 // Tile geometry shared by the channel kernels: TU x TV outputs per workgroup, shrink S
@@ -171,7 +195,6 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
     // Levels at their octave's own size (scale 1: every level i=0 with even dims) resample with
     // weights (1, 0): t = v*1*1 + 0 + 0 + 0 = v exactly -> plain copy.
     const bool ident = (L.src_h == L.nh) && (L.src_w == L.nw);
-    const float mnf = (float)mn, mxf = (float)mx;
     // uint8 images: the tile's source patch (rows r_lo..r_hi, columns c_lo..c_hi of the octave) is
     // first copied to LDS with coalesced dword loads; the 4 taps of every pixel are then LDS byte
     // reads.  (Fetched straight from HBM they were 4 byte-gathers per pixel and the texture-address
@@ -191,37 +214,44 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
         const int r_hi = t_yl.i0 > t_yl.i1 ? t_yl.i0 : t_yl.i1;
         const int c_hi = t_xl.i0 > t_xl.i1 ? t_xl.i0 : t_xl.i1;
         const int nrow = r_hi - r_lo + 1, nbyte = c_hi - c_lo + 1;
-        staged = !ident && nrow <= PROWS && nbyte + 8 <= PPITCH;
+        // strict down-scale on both axes: every tap pair is (i0, i0 + 1), no mirroring (plan.axis_taps)
+        staged = !ident && L.src_h > L.nh && L.src_w > L.nw && nrow + 1 <= PROWS && nbyte + 8 <= PPITCH;
+        WB_CSTAMP(1);
         if (staged) {
+            // LDS row r = source row r_lo + r from column c_lo on: dword loads at byte granularity
+            // (global memory takes unaligned dwords), aligned LDS stores
+            // One patch row per wave at a time, one dword per lane (no index arithmetic per element);
+            // UR rows are in flight together.  Lanes past the row end reload its last dword.
             constexpr int DWP = PPITCH / 4;                       // dwords per patch row
-            const int ndw = (nbyte + 3 + 3) / 4;                  // worst case alignment slack on both ends
-            const uint32_t m_ndw = 0xFFFFFFFFu / (uint32_t)ndw + 1u;
-            const int total = nrow * ndw;
+            const int ndw = (nbyte + 1 + 3) / 4;                  // + the (i0 + 1) neighbour of the last column
             uint32_t *pw = reinterpret_cast<uint32_t *>(uni);
-            constexpr int U = 8;
-            for (int e0 = tid; e0 < total; e0 += 256 * U) {
-                uint32_t v[U];
-                int dst[U];
+            typedef uint32_t __attribute__((aligned(1))) u32u;
+            constexpr int UR = 4;
+            const int wv = tid >> 6, ln = tid & 63;
+            for (int dw0 = 0; dw0 < ndw; dw0 += 64) {
+                int dw = dw0 + ln;
+                dw = dw < ndw ? dw : ndw - 1;
+                const T *col = src + c_lo + 4 * dw;
+                for (int r0 = wv; r0 < nrow; r0 += 4 * UR) {
+                    uint32_t v[UR];
+                    int rr[UR];
 #pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    uint32_t e = (uint32_t)(e0 + k * 256);
-                    e = e < (uint32_t)total ? e : (uint32_t)total - 1u;
-                    uint32_t row = __umulhi(e, m_ndw), dw = e - row * (uint32_t)ndw;
-                    // the row's first needed byte, aligned down to 4 (the buffers carry 16 spare bytes)
-                    uintptr_t addr = reinterpret_cast<uintptr_t>(src + (int64_t)(r_lo + (int)row) * L.src_w + c_lo) & ~(uintptr_t)3;
-                    v[k] = reinterpret_cast<const uint32_t *>(addr)[dw];
-                    dst[k] = (int)row * DWP + (int)dw;
+                    for (int k = 0; k < UR; ++k) {
+                        rr[k] = r0 + 4 * k < nrow ? r0 + 4 * k : nrow - 1;
+                        v[k] = *reinterpret_cast<const u32u *>(col + (int64_t)(r_lo + rr[k]) * L.src_w);
+                    }
+#pragma unroll
+                    for (int k = 0; k < UR; ++k) pw[rr[k] * DWP + dw] = v[k];   // duplicates rewrite the same value
                 }
-#pragma unroll
-                for (int k = 0; k < U; ++k) pw[dst[k]] = v[k];           // duplicates rewrite the same value
             }
             __syncthreads();
         }
     }
+    WB_CSTAMP(2);
     if (staged) {
         if constexpr (sizeof(T) == 1) {
             const unsigned char *patch = uni;
-            int ci0[NCS], ci1[NCS];
+            int ci0[NCS];
             float wc0f[NCS], wc1f[NCS];
             Tap tc[NCS];
 #pragma unroll
@@ -230,28 +260,70 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                 x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
                 tc[c] = ctap[x];
                 ci0[c] = tc[c].i0 - c_lo;
-                ci1[c] = tc[c].i1 - c_lo;
                 wc0f[c] = (float)tc[c].w0;
                 wc1f[c] = (float)tc[c].w1;
             }
-            const uintptr_t base = reinterpret_cast<uintptr_t>(src);
-            for (int k = wave; k < RH; k += 4) {
-                int y = ry0 + k;
-                y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
-                const Tap tr = rtap[__builtin_amdgcn_readfirstlane(y)];
-                const int i0 = __builtin_amdgcn_readfirstlane(tr.i0), i1 = __builtin_amdgcn_readfirstlane(tr.i1);
-                // byte offset of column c_lo inside the row's LDS image = its misalignment in memory
-                const int o0 = (i0 - r_lo) * PPITCH + (int)((base + (uintptr_t)((int64_t)i0 * L.src_w + c_lo)) & 3);
-                const int o1 = (i1 - r_lo) * PPITCH + (int)((base + (uintptr_t)((int64_t)i1 * L.src_w + c_lo)) & 3);
-                const float wr0 = (float)tr.w0, wr1 = (float)tr.w1;
+            // row taps: lane l holds those of tile row l (RH <= 64); a row's values reach the scalar
+            // registers by readlane, so the row loop has no memory access besides LDS
+            static_assert(RH <= 64, "one lane per tile row");
+            int ly = ry0 + (lane < RH ? lane : RH - 1);
+            ly = ly < 0 ? 0 : (ly > L.nh - 1 ? L.nh - 1 : ly);
+            const Tap trl = rtap[ly];
+            const int l_o0 = (trl.i0 - r_lo) * PPITCH;
+            const float l_wr0 = (float)trl.w0, l_wr1 = (float)trl.w1;
+            // RB rows per pass: every tap byte of the pass is requested before the first is used, and
+            // the rare exact redo is deferred behind all the fast-path arithmetic (one branch per pass)
+            constexpr int RB = 2;
+            for (int k0 = wave; k0 < RH; k0 += 4 * RB) {
+                uint8_t b[RB][NCS][4];
+                float wr0[RB], wr1[RB];
 #pragma unroll
-                for (int c = 0; c < NCS; ++c) {
-                    const unsigned char a00 = patch[o0 + ci0[c]], a01 = patch[o0 + ci1[c]];
-                    const unsigned char a10 = patch[o1 + ci0[c]], a11 = patch[o1 + ci1[c]];
-                    float out;
-                    if (!Src<T>::fast((float)a00, (float)a01, (float)a10, (float)a11, wr0, wr1, wc0f[c], wc1f[c], mnf, mxf, out))
-                        out = Src<T>::finish(resample_f64((double)a00, (double)a01, (double)a10, (double)a11, tr, tc[c]), mn, mx);
-                    R[k * RW + lane + 64 * c] = out;
+                for (int rb = 0; rb < RB; ++rb) {
+                    int k = k0 + 4 * rb;
+                    k = k < RH ? k : RH - 1;
+                    const int o0 = __builtin_amdgcn_readlane(l_o0, k);
+                    wr0[rb] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l_wr0), k));
+                    wr1[rb] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l_wr1), k));
+#pragma unroll
+                    for (int c = 0; c < NCS; ++c) {
+                        // (a00, a01) / (a10, a11) sit at i0, i0 + 1 of two consecutive patch rows
+                        const unsigned char *q = patch + o0 + ci0[c];
+                        b[rb][c][0] = q[0]; b[rb][c][1] = q[1]; b[rb][c][2] = q[PPITCH]; b[rb][c][3] = q[PPITCH + 1];
+                    }
+                }
+                float out[RB][NCS];
+                bool redo = false;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int c = 0; c < NCS; ++c)
+                        redo |= !Src<T>::fast((float)b[rb][c][0], (float)b[rb][c][1], (float)b[rb][c][2], (float)b[rb][c][3],
+                                              wr0[rb], wr1[rb], wc0f[c], wc1f[c], out[rb][c]);
+                if (redo) {                                                // rare: exact fp64 with the full taps
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) {
+                        int k = k0 + 4 * rb;
+                        k = k < RH ? k : RH - 1;
+                        int y = ry0 + k;
+                        y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
+                        const Tap tr = rtap[y];
+#pragma unroll
+                        for (int c = 0; c < NCS; ++c) {
+                            float f;
+                            if (!Src<T>::fast((float)b[rb][c][0], (float)b[rb][c][1], (float)b[rb][c][2], (float)b[rb][c][3],
+                                              wr0[rb], wr1[rb], wc0f[c], wc1f[c], f))
+                                out[rb][c] = Src<T>::finish(resample_f64((double)b[rb][c][0], (double)b[rb][c][1], (double)b[rb][c][2],
+                                                                         (double)b[rb][c][3], tr, tc[c]), mn, mx);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const int k = k0 + 4 * rb;
+                    if (k < RH) {
+#pragma unroll
+                        for (int c = 0; c < NCS; ++c) R[k * RW + lane + 64 * c] = out[rb][c];
+                    }
                 }
             }
         }
@@ -302,7 +374,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                         bool ok = false;
                         if constexpr (Src<T>::kFastResample)
                             ok = Src<T>::fast((float)v00[rb][c], (float)v01[rb][c], (float)v10[rb][c], (float)v11[rb][c],
-                                              (float)tr[rb].w0, (float)tr[rb].w1, wc0f[c], wc1f[c], mnf, mxf, out);
+                                              (float)tr[rb].w0, (float)tr[rb].w1, wc0f[c], wc1f[c], out);
                         if (!ok)
                             out = Src<T>::finish(resample_f64((double)v00[rb][c], (double)v01[rb][c], (double)v10[rb][c],
                                                               (double)v11[rb][c], tr[rb], tc[c]), mn, mx);
@@ -312,6 +384,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             }
         }
     }
+    WB_CSTAMP(3);
     if constexpr (LEFT > 0) {
         for (int p = tid; p < RH * LEFT; p += 256) {
             const int k = p / LEFT, q = MAINW + p - k * LEFT;
@@ -324,11 +397,9 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             if constexpr (sizeof(T) == 1) {
                 if (staged) {                        // the staged patch covers these columns too
                     const unsigned char *patch = uni;
-                    const uintptr_t base = reinterpret_cast<uintptr_t>(src);
-                    const int o0 = (tr.i0 - r_lo) * PPITCH + (int)((base + (uintptr_t)((int64_t)tr.i0 * L.src_w + c_lo)) & 3);
-                    const int o1 = (tr.i1 - r_lo) * PPITCH + (int)((base + (uintptr_t)((int64_t)tr.i1 * L.src_w + c_lo)) & 3);
-                    a00 = patch[o0 + tc.i0 - c_lo]; a01 = patch[o0 + tc.i1 - c_lo];
-                    a10 = patch[o1 + tc.i0 - c_lo]; a11 = patch[o1 + tc.i1 - c_lo];
+                    const int o0 = (tr.i0 - r_lo) * PPITCH + (tc.i0 - c_lo);
+                    a00 = patch[o0]; a01 = patch[o0 + 1];
+                    a10 = patch[o0 + PPITCH]; a11 = patch[o0 + PPITCH + 1];
                     from_lds = true;
                 }
             }
@@ -342,7 +413,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             if (ident) out = (float)a00;
             if constexpr (Src<T>::kFastResample)
                 if (!ok) ok = Src<T>::fast((float)a00, (float)a01, (float)a10, (float)a11, (float)tr.w0, (float)tr.w1,
-                                           (float)tc.w0, (float)tc.w1, mnf, mxf, out);
+                                           (float)tc.w0, (float)tc.w1, out);
             if (!ok) out = Src<T>::finish(resample_f64((double)a00, (double)a01, (double)a10, (double)a11, tr, tc), mn, mx);
             R[k * RW + q] = out;
         }
@@ -371,8 +442,10 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
     const double mn = Src<T>::lo(~mm[0]), mx = Src<T>::lo(mm[1]);   // mm[0] holds max(~key)
 
     const int ry0 = S * (u0 - HS) - 1, rx0 = S * (v0 - HS) - 1;
+    WB_CSTAMP(0);
     resample_tile<T, G>(a, L, src, mn, mx, ry0, rx0, R, uni, tid);
     __syncthreads();
+    WB_CSTAMP(4);
     if (a.dbg & 1) return;
 
     // ---- step 2: gradients -> 4 oriented channels -> shrink, one shrunk pixel per iteration
@@ -429,6 +502,7 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
         Sh[p] = F4{o[0], o[1], o[2], o[3]};
     }
     __syncthreads();
+    WB_CSTAMP(5);
 
     if (a.dbg & 2) return;
     // ---- step 3: 3x3 binomial smooth (fp64 sum in source order, /16, one rounding), border = 0.
@@ -462,6 +536,7 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
             o[y][0] = c.x; o[y][1] = c.y; o[y][2] = c.z; o[y][3] = c.w;
         }
     }
+    WB_CSTAMP(6);
 #pragma unroll
     for (int y = 0; y < RPT; ++y) {
         const int su = u0 + i0 + y;
@@ -471,6 +546,7 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
         float4 *dst = reinterpret_cast<float4 *>(out + ((int64_t)su * L.v + sv) * 4);
         *dst = make_float4(o[y][0], o[y][1], o[y][2], o[y][3]);
     }
+    WB_CSTAMP(7);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -675,6 +751,8 @@ void set_constants(ChanArgs &a, const double *cs_sn) {
     }
     a.chi = (float)cs_sn[5];
     a.clo = (float)(cs_sn[5] - (double)a.chi);
+    a.c2hi = (float)cs_sn[2];
+    a.c2lo = (float)(cs_sn[2] - (double)a.c2hi);
 }
 
 }  // namespace
@@ -770,3 +848,26 @@ extern "C" int wb_selftest_projection(void *stream, uint32_t *mismatches) {
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;
 }
+
+
+#ifdef WB_CASC_STAMPS
+#include <vector>
+// Diagnostic build: mean microseconds between consecutive stamps over the first n_wg workgroups of
+// the last channel launch (s_memrealtime ticks at 100 MHz).  Workgroups that skipped a phase
+// (direct path) contribute 0 to it.
+extern "C" int wb_debug_channel_stamps(int n_wg, double *mean_us7, double *lifetime_us) {
+    if (n_wg > WB_CSTAMP_WGS) n_wg = WB_CSTAMP_WGS;
+    std::vector<unsigned long long> h((size_t)n_wg * WB_CSTAMP_SLOTS);
+    WB_HIP_CHECK(hipDeviceSynchronize());
+    WB_HIP_CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_chan_stamps), h.size() * 8));
+    double acc[7] = {0}, life = 0;
+    for (int w = 0; w < n_wg; ++w) {
+        const unsigned long long *s = &h[(size_t)w * WB_CSTAMP_SLOTS];
+        for (int k = 0; k < 7; ++k) acc[k] += (double)(s[k + 1] - s[k]);
+        life += (double)(s[7] - s[0]);
+    }
+    for (int k = 0; k < 7; ++k) mean_us7[k] = acc[k] / n_wg / 100.0;
+    *lifetime_us = life / n_wg / 100.0;
+    return WB_OK;
+}
+#endif
