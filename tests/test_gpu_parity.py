@@ -77,6 +77,28 @@ def test_channel_pyramid_vs_oracle(shape, dtype):
         assert np.array_equal(bits(c), bits(rc))
 
 
+def test_clean_edges_hit_the_projection_leftovers():
+    """Noise-free blocks, ramps and 45-degree edges: gy == 0 / gx == +-gy over whole 2x2 blocks, so the
+    1e-13..1e-16-sized leftovers of the fp64 projection survive the shrink and reach the smooth
+    (the kernel's exact-order path for tiles holding such values)."""
+    H, W = 160, 224
+    y, x = np.mgrid[0:H, 0:W]
+    img = np.full((H, W), 40, np.uint8)
+    img[20:70, 30:90] = 200                                   # axis-aligned square
+    img[(x - y > 60) & (x - y < 110) & (y > 80)] = 120        # 45-degree band
+    img[(x + y > 250) & (x + y < 290) & (y < 75)] = 90        # -45-degree band
+    img[100:150, 10:60] = (np.arange(50) * 3)[None, :]        # horizontal ramp (gy == 0 everywhere)
+    for o in (dict(shrink=2, n_per_oct=4, smooth=1), dict(shrink=1, n_per_oct=2, smooth=1), dict(shrink=2, n_per_oct=2, smooth=0)):
+        got = list(wb.channels.channel_pyramid(img, dict(o, channels=wb.channels.grad_hist)))
+        ref = list(orc.channel_pyramid(img, dict(o, channels=orc.grad_hist)))
+        assert len(got) == len(ref) > 0
+        tiny = 0
+        for (c, s), (rc, rs) in zip(got, ref):
+            assert s == rs and np.array_equal(bits(c), bits(rc))
+            tiny += int(((rc > 0) & (rc < 1e-6)).sum())
+        assert tiny > 0, "the image no longer produces leftover values"
+
+
 def test_shrink4_extension_vs_oracle():
     img = synth_image(200, 300, 5)
     o = dict(shrink=4, n_per_oct=3, smooth=1)

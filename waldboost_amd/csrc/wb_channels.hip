@@ -428,7 +428,10 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
     constexpr int UNI_BYTES = G::SH_BYTES > PATCH_BYTES ? G::SH_BYTES : PATCH_BYTES;
     __shared__ float R[RH * RW];
     __shared__ __attribute__((aligned(16))) unsigned char uni[UNI_BYTES];
+    __shared__ uint32_t odd_values;      // set when a shrunk value lies outside the exact-sum range (see step 3)
     F4 *Sh = reinterpret_cast<F4 *>(uni);
+    constexpr bool SEPARABLE = SMOOTH && FAST;
+    if (SEPARABLE && threadIdx.x == 0) odd_values = 0;
 
     const WbTile tile = a.tiles[blockIdx.x];
     const WbLevel L = a.levels[tile.level];
@@ -500,6 +503,14 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
             }
         }
         Sh[p] = F4{o[0], o[1], o[2], o[3]};
+        if constexpr (SEPARABLE) {
+            // integer gradients: a shrunk value is 0, or in [0.17, 1443] (some pixel of the block had a
+            // gradient), or a sum of the 1e-13-sized leftovers of the projection -- flag the last kind
+            const uint32_t lo = __float_as_uint(0.125f) - 1u;
+            const uint32_t m01 = min(__float_as_uint(o[0]) - 1u, __float_as_uint(o[1]) - 1u);
+            const uint32_t m23 = min(__float_as_uint(o[2]) - 1u, __float_as_uint(o[3]) - 1u);
+            if (min(m01, m23) < lo) odd_values = 1;
+        }
     }
     __syncthreads();
     WB_CSTAMP(5);
@@ -515,20 +526,39 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
     const int sv = v0 + j;
     float o[RPT][4];
     if constexpr (SMOOTH) {
-        double w[RPT + 2][3][4];
+        if (SEPARABLE && odd_values == 0) {
+            // Every value of the tile is 0 or a float32 in [2^-3, 2^11): all partial sums of the nine
+            // weighted terms are multiples of 2^-26 below 2^15 -- exact in fp64 in ANY order.  So the
+            // row sums are formed once, row by row, and shared by the three output rows that use them.
+            double s[3][4];
 #pragma unroll
-        for (int y = 0; y < RPT + 2; ++y)
+            for (int y = 0; y < RPT + 2; ++y) {
+                const F4 c0 = Sh[(i0 + y) * SV + j], c1 = Sh[(i0 + y) * SV + j + 1], c2 = Sh[(i0 + y) * SV + j + 2];
+                const float a0[4] = {c0.x, c0.y, c0.z, c0.w}, a1[4] = {c1.x, c1.y, c1.z, c1.w}, a2[4] = {c2.x, c2.y, c2.z, c2.w};
 #pragma unroll
-            for (int x = 0; x < 3; ++x) {
-                F4 c = Sh[(i0 + y) * SV + (j + x)];
-                w[y][x][0] = (double)c.x; w[y][x][1] = (double)c.y; w[y][x][2] = (double)c.z; w[y][x][3] = (double)c.w;
+                for (int k = 0; k < 4; ++k) s[y % 3][k] = __builtin_fma(2.0, (double)a1[k], (double)a0[k]) + (double)a2[k];
+                if (y >= 2) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        o[y - 2][k] = (float)((__builtin_fma(2.0, s[(y - 1) % 3][k], s[(y - 2) % 3][k]) + s[y % 3][k]) * 0.0625);
+                }
             }
+        } else {
+            double w[RPT + 2][3][4];
 #pragma unroll
-        for (int y = 0; y < RPT; ++y)
+            for (int y = 0; y < RPT + 2; ++y)
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                o[y][k] = smooth9(w[y][0][k], w[y][1][k], w[y][2][k], w[y + 1][0][k], w[y + 1][1][k], w[y + 1][2][k],
-                                  w[y + 2][0][k], w[y + 2][1][k], w[y + 2][2][k]);
+                for (int x = 0; x < 3; ++x) {
+                    F4 c = Sh[(i0 + y) * SV + (j + x)];
+                    w[y][x][0] = (double)c.x; w[y][x][1] = (double)c.y; w[y][x][2] = (double)c.z; w[y][x][3] = (double)c.w;
+                }
+#pragma unroll
+            for (int y = 0; y < RPT; ++y)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o[y][k] = smooth9(w[y][0][k], w[y][1][k], w[y][2][k], w[y + 1][0][k], w[y + 1][1][k], w[y + 1][2][k],
+                                      w[y + 2][0][k], w[y + 2][1][k], w[y + 2][2][k]);
+        }
     } else {
 #pragma unroll
         for (int y = 0; y < RPT; ++y) {
