@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 FUNCS = {"grad_hist_4_u1": wb.fpga.grad_hist_4_u1, "grad_mag_u1": wb.fpga.grad_mag_u1}
 U1_CASES = [c for c in f2_cases() if c[2]["channels"] in FUNCS]
+GM_CASES = [c for c in f2_cases() if c[2]["channels"] == "grad_mag"]
 
 
 def bits(a):
@@ -153,3 +154,58 @@ def test_u1_1080p_vs_oracle():
     assert np.array_equal(res["alive"], ref["alive"])
     assert np.array_equal(res["r"], ref["r"]) and np.array_equal(res["c"], ref["c"]) and np.array_equal(res["level"], ref["level"])
     assert np.array_equal(bits(res["scores"]), bits(ref["scores"]))
+
+
+# ------------------------------------------------------------------------------ grad_mag (float32, 1 channel)
+@pytest.mark.parametrize("case", GM_CASES, ids=lambda c: c[0])
+def test_grad_mag_pyramid_bit_exact_vs_reference_fixture(case):
+    name, img, info, levels = case
+    opts = dict(shrink=info["shrink"], n_per_oct=info["n_per_oct"], smooth=info["smooth"], channels=wb.channels.grad_mag)
+    got = list(wb.channels.channel_pyramid(img, opts))
+    assert len(got) == info["n_levels"]
+    for i, ((c, s), ref, rs) in enumerate(zip(got, levels, info["scales"])):
+        assert c.dtype == np.float32 and c.shape == ref.shape, (name, i)
+        assert s == rs
+        assert np.array_equal(bits(c), bits(ref)), (name, i, np.abs(c - ref).max())
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("shape,shrink", [((8, 8), 2), ((9, 23), 2), ((131, 97), 2), ((480, 640), 2), ((150, 211), 1),
+                                          ((200, 300), 4)])
+def test_grad_mag_pyramid_vs_oracle(shape, shrink, dtype):
+    img = synth_image(shape[0], shape[1], 41, dtype)
+    o = dict(shrink=shrink, n_per_oct=4 if shrink != 2 else 8, smooth=1)
+    got = list(wb.channels.channel_pyramid(img, dict(o, channels=wb.channels.grad_mag)))
+    ref = list(orc.channel_pyramid(img, dict(o, channels="grad_mag")))
+    assert len(got) == len(ref)
+    for (c, s), (rc, rs) in zip(got, ref):
+        assert s == rs and c.shape == rc.shape and c.dtype == np.float32
+        assert np.array_equal(bits(c), bits(rc))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_grad_mag_on_a_bare_image(dtype):
+    for shape in [(77, 103), (5, 40), (3, 3)]:          # the small ones reflect more than once inside the 11-tap filter
+        img = synth_image(shape[0], shape[1], 9, dtype)
+        got = wb.channels.grad_mag(img)
+        ref = orc.grad_mag(img)
+        assert got.shape == ref.shape and np.array_equal(bits(got), bits(ref))
+    with pytest.raises(NotImplementedError):
+        wb.channels.grad_mag(img, norm=3)
+
+
+def test_grad_mag_detect_vs_reference_fixture():
+    fn = "grad_mag"
+    meta = f2_meta()
+    g = np.load(os.path.join(GOLDEN, f"{fn}_200x264.npz"))
+    M = wb.load(os.path.join(GOLDEN, f"{fn}_d2_T24.pb"))
+    assert M.channel_opts["channels"] is wb.channels.grad_mag
+    assert wb.model.symbol_name(M.channel_opts["channels"]) == meta["names"][fn] == "waldboost.channels.grad_mag"
+    res = M.detect_raw(g["image"])
+    det = g["det"]
+    assert det.size > 0
+    assert M.n_loc == int(g["n_loc"]) and M.n_weak == int(g["n_weak"])
+    assert np.array_equal(res["alive"], g["alive"])
+    assert np.array_equal(res["level"], det["level"]) and np.array_equal(res["r"], det["r"]) and np.array_equal(res["c"], det["c"])
+    assert np.array_equal(bits(res["scores"]), bits(det["score"]))
+    assert np.array_equal(bits(res["boxes"]), bits(np.stack([det["x1"], det["y1"], det["x2"], det["y2"]], 1)))

@@ -27,4 +27,5 @@ SPECS = {
                                   "waldboost.fpga.channels.grad_hist_4_u1"),
     "grad_mag_u1": ChannelSpec("grad_mag_u1", nat.WB_CHN_GRAD_MAG_U1, 1, np.uint8,
                                "waldboost.fpga.channels.grad_mag_u1"),
+    "grad_mag": ChannelSpec("grad_mag", nat.WB_CHN_GRAD_MAG, 1, np.float32, "waldboost.channels.grad_mag"),
 }

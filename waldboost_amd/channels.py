@@ -6,6 +6,8 @@ kernels in csrc/wb_channels.hip.  Channel functions with a kernel:
 
   ``grad_hist(image)``            reference channels.py:40-52, default arguments
                                   (n_bins=4, full=False, bias=0)          -> float32 [H,W,4]
+  ``grad_mag(image)``             reference channels.py:30-37, default arguments
+                                  (norm=5, eps=1e-3)                      -> float32 [H,W,1]
   ``fpga.grad_hist_4_u1(image)``  reference fpga/channels.py:29-53        -> uint8   [H,W,4]
   ``fpga.grad_mag_u1(image)``     reference fpga/channels.py:56-67        -> uint8   [H,W,1]
 """
@@ -45,6 +47,14 @@ def grad_hist(image, n_bins=4, full=False, bias=0):
     return _on_bare_image(image.astype("f"), SPECS["grad_hist"])
 
 
+def grad_mag(image, norm=5, eps=1e-3):
+    """Gradient magnitude divided by its 11-tap-triangle-filtered self -> float32 [H,W,1]."""
+    if norm != 5 or eps != 1e-3:
+        raise NotImplementedError("the HIP grad_mag kernel implements the defaults norm=5, eps=1e-3")
+    _validate_image(image)
+    return _on_bare_image(image.astype("f"), SPECS["grad_mag"])
+
+
 def grad_hist_4_u1(image):
     """8 bit image -> 4 integer orientation channels, uint8 [H,W,4] (reference fpga/channels.py:29-53)."""
     _validate_image(image)
@@ -68,6 +78,7 @@ def _require_u8(image, name):
 SPECS["grad_hist"].func = grad_hist
 SPECS["grad_hist_4_u1"].func = grad_hist_4_u1
 SPECS["grad_mag_u1"].func = grad_mag_u1
+SPECS["grad_mag"].func = grad_mag
 
 # Names a stored model may use for its channel function (reference model.py:302 writes
 # module.qualname; model.py:27-29 evals it on load -- replaced here by this allow-list).

@@ -32,6 +32,8 @@ struct ChanArgs {
     double cs[4], sn[4];
     float chi, clo;      // sin(pi/4) = chi + clo (two-float split) for the integer-gradient fast path
     float c2hi, c2lo;    // cos(pi/2) (fp64: 6.1e-17) likewise
+    double tri[11];      // grad_mag: triangle_kernel(5) (float32 values, widened)
+    float gm_eps;        // grad_mag: float32(1e-3)
     int dbg;             // diagnostics (WB_CHAN_DBG): 1 = stop after step 1, 2 = after step 2, 4 = skip the stores
 };
 
@@ -744,6 +746,166 @@ int launch_dtype(hipStream_t st, dim3 grid, const ChanArgs &a, int shrink, bool 
     return WB_OK;
 }
 
+// -------------------------------------------------------------------------------------------
+// waldboost.channels.grad_mag (reference channels.py:11-37, defaults norm=5, eps=1e-3): one float32
+// channel  mag / (triangle11(mag) + eps),  mag = sqrt(gx^2 + gy^2) in fp32.  The normaliser is
+// scipy's convolve1d twice (rows, then columns) with the 11-tap triangle: symmetric-kernel branch
+// of NI_Correlate1D, fp64 accumulation  t = x[l]*w[c];  t += (x[l+j] + x[l-j]) * w[c+j], j = -5..-1,
+// one fp32 rounding per pass, 'reflect' borders.  The tile therefore carries a 5-pixel halo of mag
+// (6 of the resized image); halo positions outside the level hold the REFLECTED coordinate's
+// pixel, under which the gradient magnitude of the mirror position comes out exactly (the [1,2,1]
+// pass is symmetric, the difference pass only changes sign).  Secondary channel function: plain
+// per-pixel code, not tuned like channels_kernel.
+struct GmGeom {
+    static constexpr int NH = 5;      // half width of the 11-tap triangle
+};
+
+__device__ inline int reflect_index(int i, int n) {      // scipy 'reflect': (d c b a | a b c d | d c b a)
+    const int period = 2 * n;
+    i %= period;
+    if (i < 0) i += period;
+    return i >= n ? period - 1 - i : i;
+}
+
+template <typename T, int S, int TU, int TV, bool SMOOTH>
+__global__ __launch_bounds__(256) void channels_gm_kernel(ChanArgs a) {
+    constexpr int HS = SMOOTH ? 1 : 0, NH = GmGeom::NH;
+    constexpr int SU = TU + 2 * HS, SV = TV + 2 * HS;      // shrunk tile incl. smooth halo
+    constexpr int VH = S * SU, VW = S * SV;                // normalised magnitudes needed
+    constexpr int MH = VH + 2 * NH, MW = VW + 2 * NH;      // magnitudes incl. the triangle halo
+    constexpr int RH = MH + 2, RW = MW + 2;                // resized pixels incl. the gradient halo
+    __shared__ float R[RH * RW];                           // resized tile; later the row-pass result [VH][MW]
+    __shared__ float Mg[MH * MW];                          // magnitudes; the centre is normalised in place
+    __shared__ float Sh[SU * SV];
+    static_assert(VH * MW <= RH * RW, "row-pass result reuses the resized tile");
+
+    const WbTile tile = a.tiles[blockIdx.x];
+    const WbLevel L = a.levels[tile.level];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int u0 = tile.ty * TU, v0 = tile.tx * TV;
+    const T *src = (L.oct == 0) ? (const T *)a.img + (int64_t)b * a.img_stride
+                                : (const T *)a.oct + (int64_t)b * a.oct_stride + L.src_off;
+    const uint32_t *mm = a.minmax + ((int64_t)b * a.n_oct + L.oct) * 2;
+    const double mn = Src<T>::lo(~mm[0]), mx = Src<T>::lo(mm[1]);
+    const Tap *__restrict__ rtap = a.taps + L.tap_off;
+    const Tap *__restrict__ ctap = rtap + L.nh;
+    const bool ident = (L.src_h == L.nh) && (L.src_w == L.nw);
+    const int ry0 = S * (u0 - HS) - NH - 1, rx0 = S * (v0 - HS) - NH - 1;
+
+    // ---- resized pixels (reference channels.py:132), reflected outside the level
+    for (int p = tid; p < RH * RW; p += 256) {
+        const int k = p / RW, q = p - k * RW;
+        const int y = reflect_index(ry0 + k, L.nh), x = reflect_index(rx0 + q, L.nw);
+        const Tap tr = rtap[y], tc = ctap[x];
+        const T *r0 = src + (int64_t)tr.i0 * L.src_w, *r1 = src + (int64_t)tr.i1 * L.src_w;
+        const T a00 = r0[tc.i0], a01 = r0[tc.i1], a10 = r1[tc.i0], a11 = r1[tc.i1];
+        float out = 0.0f;
+        bool ok = ident;
+        if (ident) out = (float)a00;
+        if constexpr (Src<T>::kFastResample)
+            if (!ok) ok = Src<T>::fast((float)a00, (float)a01, (float)a10, (float)a11, (float)tr.w0, (float)tr.w1,
+                                       (float)tc.w0, (float)tc.w1, out);
+        if (!ok) out = Src<T>::finish(resample_f64((double)a00, (double)a01, (double)a10, (double)a11, tr, tc), mn, mx);
+        R[p] = out;
+    }
+    __syncthreads();
+
+    // ---- gradient magnitude (channels.py:16-21, 31-32): fp32 squares, sum and square root
+    for (int p = tid; p < MH * MW; p += 256) {
+        const int k = p / MW, q = p - k * MW;
+        const float *c = R + k * RW + q;                      // 3x3 patch, centre at (k+1, q+1)
+        const float hc0 = Src<T>::hpass(c[0], c[RW], c[2 * RW]);              // vertical [1,2,1] at column q
+        const float hc2 = Src<T>::hpass(c[2], c[RW + 2], c[2 * RW + 2]);      //                     column q+2
+        const float hr0 = Src<T>::hpass(c[0], c[1], c[2]);                    // horizontal [1,2,1] at row k
+        const float hr2 = Src<T>::hpass(c[2 * RW], c[2 * RW + 1], c[2 * RW + 2]);
+        const float gx = Src<T>::dpass(hc0, hc2), gy = Src<T>::dpass(hr0, hr2);
+        Mg[p] = sqrtf(gx * gx + gy * gy);
+    }
+    __syncthreads();
+
+    // ---- triangle filter along the rows' axis (convolve1d axis 0), result over the resized tile's memory
+    float *Tv = R;
+    for (int p = tid; p < VH * MW; p += 256) {
+        const int k = p / MW, q = p - k * MW;
+        const float *c = Mg + (k + NH) * MW + q;
+        double t = (double)c[0] * a.tri[NH];
+#pragma unroll
+        for (int j = -NH; j < 0; ++j) t = t + ((double)c[j * MW] + (double)c[-j * MW]) * a.tri[NH + j];
+        Tv[p] = (float)t;
+    }
+    __syncthreads();
+    // ---- ... along the columns' axis, then mag / (norm + eps), in place at the centre of Mg
+    for (int p = tid; p < VH * VW; p += 256) {
+        const int k = p / VW, q = p - k * VW;
+        const float *c = Tv + k * MW + q + NH;
+        double t = (double)c[0] * a.tri[NH];
+#pragma unroll
+        for (int j = -NH; j < 0; ++j) t = t + ((double)c[j] + (double)c[-j]) * a.tri[NH + j];
+        float *m = Mg + (k + NH) * MW + q + NH;
+        *m = *m / ((float)t + a.gm_eps);
+    }
+    __syncthreads();
+
+    // ---- shrink (channels.py:55-64, fp32 ((a+b)+c)+d then /4)
+    for (int p = tid; p < SU * SV; p += 256) {
+        const int i = p / SV, j = p - i * SV;
+        auto at = [&](int y, int x) { return Mg[(S * i + y + NH) * MW + S * j + x + NH]; };
+        float o;
+        if constexpr (S == 1) {
+            o = at(0, 0);
+        } else if constexpr (S == 2) {
+            o = (((at(0, 0) + at(1, 0)) + at(0, 1)) + at(1, 1)) * 0.25f;
+        } else {
+            float qd[2][2];
+#pragma unroll
+            for (int A = 0; A < 2; ++A)
+#pragma unroll
+                for (int B = 0; B < 2; ++B)
+                    qd[A][B] = (((at(2 * A, 2 * B) + at(2 * A + 1, 2 * B)) + at(2 * A, 2 * B + 1)) + at(2 * A + 1, 2 * B + 1)) * 0.25f;
+            o = (((qd[0][0] + qd[1][0]) + qd[0][1]) + qd[1][1]) * 0.25f;
+        }
+        Sh[p] = o;
+    }
+    __syncthreads();
+
+    // ---- 3x3 smooth (fp64, source order), border 0, store [u][v][1]
+    float *out = reinterpret_cast<float *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
+    for (int p = tid; p < TU * TV; p += 256) {
+        const int i = p / TV, j = p - i * TV;
+        const int su = u0 + i, sv = v0 + j;
+        if (su >= L.u || sv >= L.v) continue;
+        float o;
+        if constexpr (SMOOTH) {
+            const float *c = Sh + i * SV + j;
+            o = smooth9(c[0], c[1], c[2], c[SV], c[SV + 1], c[SV + 2], c[2 * SV], c[2 * SV + 1], c[2 * SV + 2]);
+            if (su == 0 || sv == 0 || su == L.u - 1 || sv == L.v - 1) o = 0.0f;
+        } else {
+            o = Sh[i * SV + j];
+        }
+        out[(int64_t)su * L.v + sv] = o;
+    }
+}
+
+template <typename T>
+int launch_gm(hipStream_t st, dim3 grid, const ChanArgs &a, int shrink, bool smooth) {
+#define WB_GM(S, TU, TV)                                                                         \
+    if (smooth)                                                                                  \
+        hipLaunchKernelGGL((channels_gm_kernel<T, S, TU, TV, true>), grid, dim3(256), 0, st, a); \
+    else                                                                                         \
+        hipLaunchKernelGGL((channels_gm_kernel<T, S, TU, TV, false>), grid, dim3(256), 0, st, a);
+    switch (shrink) {                      // same output tiles as the other channel kernels (wb_channels_tile)
+        case 1: WB_GM(1, 16, 64) break;
+        case 2: WB_GM(2, 16, 64) break;
+        case 4: WB_GM(4, 8, 32) break;
+        default:
+            wb_set_error("wb_channels_launch: shrink=%d unsupported (1, 2; 4 as an extension)", shrink);
+            return WB_ERR_UNSUPPORTED;
+    }
+#undef WB_GM
+    WB_HIP_CHECK(hipGetLastError());
+    return WB_OK;
+}
+
 template <int NCH>
 int launch_u1(hipStream_t st, dim3 grid, const ChanArgs &a, int shrink, bool smooth) {
 #define WB_U1(S, TU, TV)                                                                        \
@@ -819,7 +981,8 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
                                   int n_levels, const WbTile *tiles, int n_tiles, const uint32_t *minmax,
                                   int n_oct, const WbTap *taps, int channel_func, int shrink, int smooth,
                                   const double *cs_sn, void *chn, int64_t chn_stride) {
-    WB_REQUIRE(img && levels && tiles && minmax && taps && cs_sn && chn, "wb_channels_launch: null pointer");
+    WB_REQUIRE(img && levels && tiles && minmax && taps && chn, "wb_channels_launch: null pointer");
+    WB_REQUIRE(cs_sn || channel_func != WB_CHN_GRAD_HIST, "wb_channels_launch: grad_hist needs the orientation constants");
     WB_REQUIRE(batch >= 1 && n_levels >= 1 && n_tiles >= 1, "wb_channels_launch: empty launch");
     WB_REQUIRE(batch <= 65535, "wb_channels_launch: batch %d exceeds grid.y limit", batch);
     WB_REQUIRE(smooth == 0 || smooth == 1, "wb_channels_launch: smooth must be 0 or 1");
@@ -836,7 +999,7 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
     a.n_oct = n_oct;
     a.chn = chn;
     a.chn_stride = chn_stride;
-    set_constants(a, cs_sn);
+    if (cs_sn) set_constants(a, cs_sn);
     static const int dbg = getenv("WB_CHAN_DBG") ? atoi(getenv("WB_CHAN_DBG")) : 0;
     a.dbg = dbg;
     dim3 grid((unsigned)n_tiles, (unsigned)batch);
@@ -848,6 +1011,15 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
         }
         return channel_func == WB_CHN_GRAD_HIST_4_U1 ? launch_u1<4>(st, grid, a, shrink, smooth != 0)
                                                      : launch_u1<1>(st, grid, a, shrink, smooth != 0);
+    }
+    if (channel_func == WB_CHN_GRAD_MAG) {
+        // H = (1,2,..,6,..,2,1) as float32, divided by its float32 sum (channels.py:11-13)
+        for (int i = 0; i < 11; ++i) a.tri[i] = (double)((float)(i < 6 ? i + 1 : 11 - i) / 36.0f);
+        a.gm_eps = 1e-3f;
+        if (dtype == WB_DTYPE_U8) return launch_gm<uint8_t>(st, grid, a, shrink, smooth != 0);
+        if (dtype == WB_DTYPE_F32) return launch_gm<float>(st, grid, a, shrink, smooth != 0);
+        wb_set_error("wb_channels_launch: unsupported dtype %d (uint8 and float32 images only)", dtype);
+        return WB_ERR_UNSUPPORTED;
     }
     if (channel_func != WB_CHN_GRAD_HIST) {
         wb_set_error("wb_channels_launch: channel function %d has no kernel", channel_func);

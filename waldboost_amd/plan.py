@@ -48,7 +48,8 @@ class PyramidPlan:
         self.H, self.W = int(H), int(W)
         self.shrink, self.n_per_oct, self.smooth = int(shrink), int(n_per_oct), int(smooth)
         self.n_chn, self.chn_bytes = int(n_chn), int(chn_bytes)     # channels per pixel, bytes per channel value
-        self.octaves = octave_shapes(H, W)
+        # exact_single: one level at the image's own size, whatever that size is
+        self.octaves = [(self.H, self.W)] if exact_single else octave_shapes(H, W)
         self.n_oct = len(self.octaves)
         off, acc = [], 0
         for k, (h, w) in enumerate(self.octaves):
@@ -62,8 +63,6 @@ class PyramidPlan:
         if exact_single:
             # one level at the image's own size (grad_hist on a bare image: no resize rounding)
             levels.append(dict(oct=0, h=self.H, w=self.W, nh=self.H, nw=self.W, scale=1.0))
-            self.octaves = [(self.H, self.W)]
-            self.n_oct = 1
         else:
             factor = 2 ** (-1 / n_per_oct)
             for o, (h, w) in enumerate(self.octaves):
