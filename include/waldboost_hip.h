@@ -28,6 +28,9 @@
  *        -> wb_tree_eval_launch
  *   reference waldboost/model.py:136-147 (Model.get_boxes)
  *        -> wb_boxes_launch
+ *   reference waldboost/samples.py:14-43 (gather_samples), waldboost/model.py:181-214 (Model.predict),
+ *        waldboost/training.py:73-83 (DTree.apply/predict): the training-time callers of the hot path
+ *        -> wb_gather_samples_launch, wb_samples_predict_launch, wb_tree_apply_launch
  */
 #ifndef WALDBOOST_HIP_H
 #define WALDBOOST_HIP_H
@@ -211,6 +214,26 @@ int wb_tree_eval_launch(void *stream, const void *X, int x_dtype, int u, int v, 
                         const int32_t *cs, int64_t n_pos, const uint8_t *feature,
                         const float *threshold, const int8_t *left, const int8_t *right,
                         const float *prediction, int n_nodes, float *out);
+
+/* Crops of m x n windows of an HWC channel image X[u][v][C] (x_dtype: WB_DTYPE_F32 / WB_DTYPE_U8) at the
+ * origins (rs[i], cs[i]) -> out[n_pos][m][n][C] of the same dtype (reference samples.py:14-43
+ * gather_samples, the crop step of hard-negative mining).  Origins must satisfy rs+m <= u, cs+n <= v
+ * (the host wrapper checks).  All pointers dev. */
+int wb_gather_samples_launch(void *stream, const void *X, int x_dtype, int u, int v, int C, const int32_t *rs,
+                             const int32_t *cs, int64_t n_pos, int m, int n, void *out);
+
+/* The cascade on per-sample arrays X[n_samples][m][n][C] (reference model.py:181-214 Model.predict, the
+ * re-scoring step of the training sample pool): H[i] = accumulated response in stage order while the
+ * sample is alive, -inf once a stage rejected it; mask[i] (uint8) = 1 if it passed every stage. */
+int wb_samples_predict_launch(void *stream, const WbModel *model, const void *X, int x_dtype,
+                              int64_t n_samples, float *H, uint8_t *mask);
+
+/* One tree on per-sample arrays X[n_samples][m][n][C]: node[i] = index of the leaf reached (reference
+ * training.py:73-83 DTree.apply; DTree.predict is prediction[node]).  Tree arrays dev, as for
+ * wb_tree_eval_launch. */
+int wb_tree_apply_launch(void *stream, const void *X, int x_dtype, int64_t n_samples, int m, int n, int C,
+                         const uint8_t *feature, const float *threshold, const int8_t *left,
+                         const int8_t *right, int n_nodes, int32_t *node);
 
 /* XYXY float32 boxes of detections: [c, r, c+n, r+m] * (1/scale[level]) (model.py:136-147).
  *   inv_scale  dev float[n_levels] = float32(1.0/scale) computed on the host in fp64 */

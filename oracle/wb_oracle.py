@@ -22,6 +22,9 @@ computes under NumPy 2.x / SciPy 1.15 for
   * ``waldboost.model.Model.predict_on_image``  (reference model.py:216-259)
   * ``waldboost.training.DTree.predict_on_image`` (reference training.py:84-96)
   * ``waldboost.model.Model.get_boxes/detect``  (reference model.py:136-179)
+  * ``waldboost.samples.gather_samples``        (reference samples.py:14-43)
+  * ``waldboost.model.Model.predict`` / ``DTree.apply`` on samples
+                                                (reference model.py:181-214, training.py:73-83)
 
 Parity pinning: checked against (a) the reference's own source files imported
 from /root/reference with its four missing leaf dependencies stubbed
@@ -43,6 +46,7 @@ __all__ = [
     "grad_hist", "grad_mag", "grad_hist_4_u1", "grad_mag_u1", "triangle_kernel", "CHANNEL_FUNCS",
     "avg_pool_2", "smooth_image_3d", "channel_pyramid",
     "tree_predict_on_image", "cascade_predict_on_image", "get_boxes", "detect",
+    "gather_samples", "tree_apply", "model_predict",
 ]
 
 
@@ -442,3 +446,40 @@ def detect(shape, channel_opts, trees, thetas, image):
         c=np.concatenate(cc) if cc else np.empty(0, np.int64),
         alive=alive, n_loc=int(n_loc), n_weak=int(alive.sum()), scales=scales,
     )
+
+
+# --------------------------------------------------------------------------- f4: training-time callers
+def gather_samples(chns, rs, cs, shape):
+    """reference samples.py:14-43."""
+    if rs.size != cs.size:
+        raise ValueError("Sizes of 'rs' and 'cs' must match")
+    m, n, _ = shape
+    if rs.size == 0:
+        return np.empty((0,) + tuple(shape), dtype=chns.dtype)
+    return np.array([chns[r:r + m, c:c + n, ...] for r, c in zip(rs, cs)])
+
+
+def tree_apply(tree, X):
+    """reference training.py:73-81: leaf index per sample X[i] of shape (m, n, C)."""
+    node = np.zeros(X.shape[0], "i")
+    for n in np.flatnonzero(tree["left"] >= 0):
+        r, c, ch = (int(x) for x in tree["feature"][n])
+        idx = np.flatnonzero(node == n)
+        b = X[idx, r, c, ch] <= tree["threshold"][n]
+        node[idx] = np.where(b, tree["left"][n], tree["right"][n])
+    return node
+
+
+def model_predict(shape, trees, thetas, X):
+    """reference model.py:181-214: (H, mask) of the cascade on samples X[N, m, n, C]."""
+    n = X.shape[0]
+    assert tuple(X.shape[1:]) == tuple(shape)
+    H = np.zeros(n, np.float32)
+    mask = np.ones(n, bool)
+    for tree, theta in zip(trees, thetas):
+        H[mask] += tree["prediction"][tree_apply(tree, X[mask, ...])]
+        if theta == -np.inf:
+            continue
+        mask = np.logical_and(mask, H >= theta)
+    H[~mask] = -np.inf
+    return H, mask

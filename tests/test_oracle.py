@@ -144,6 +144,28 @@ def test_grad_mag_equals_scipy():
         assert np.array_equal(orc.grad_mag(img).view(np.uint32), mag[..., None].view(np.uint32))
 
 
+# ---- training-time callers: gather_samples, Model.predict, DTree.apply ----
+@pytest.mark.parametrize("tag,pb,npz", [("f32", "mixed_d2_T24.pb", "mixed_200x264.npz"),
+                                        ("u8", "grad_hist_4_u1_d2_T24.pb", "grad_hist_4_u1_200x264.npz")])
+def test_f4_samples_match_reference(tag, pb, npz):
+    from util import oracle_model
+    z = np.load(os.path.join(GOLDEN, "samples_f4.npz"))
+    M = wb.load(os.path.join(GOLDEN, pb))
+    shape, opts, trees, thetas = oracle_model(M)
+    levels = list(orc.channel_pyramid(np.load(os.path.join(GOLDEN, npz))["image"], opts))
+    for li in (0, 5):
+        k = f"{tag}/L{li}"
+        X = orc.gather_samples(levels[li][0], z[f"{k}/rs"], z[f"{k}/cs"], shape)
+        assert X.dtype == z[f"{k}/X"].dtype and np.array_equal(X, z[f"{k}/X"])
+        H, mask = orc.model_predict(shape, trees, thetas, X)
+        assert np.array_equal(mask, z[f"{k}/mask"]) and mask.any() and not mask.all()
+        assert np.array_equal(H.view(np.uint32), z[f"{k}/H"].view(np.uint32))
+        for t in (0, 3, 10):
+            assert np.array_equal(orc.tree_apply(trees[t], X), z[f"{k}/apply{t}"])
+            assert np.array_equal(trees[t]["prediction"][orc.tree_apply(trees[t], X)], z[f"{k}/predict{t}"])
+    assert orc.gather_samples(levels[0][0], np.zeros(0, int), np.zeros(0, int), shape).shape == (0,) + shape
+
+
 # ---- SciPy known-answer tests (SciPy ships on the GPU box as well) -------------------------
 @pytest.mark.parametrize("shape,out", [((1080 // 4, 1920 // 4), (990 // 4 * 1, 1760 // 4)), ((97, 131), (80, 110)),
                                        ((64, 96), (64, 96)), ((33, 60), (24, 42)), ((135, 240), (134, 240))])

@@ -53,6 +53,9 @@ SYMBOLS = {
                                     C.c_uint32, _P, _P]),
     "wb_tree_eval_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P, _P, _P, _P, _P,
                                       C.c_int, _P]),
+    "wb_gather_samples_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "wb_samples_predict_launch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P]),
+    "wb_tree_apply_launch": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "wb_boxes_launch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int, C.c_int, _P, _P]),
     "wb_selftest_projection": (C.c_int, [_P, _P]),
 }

@@ -56,3 +56,17 @@ def concatenate(boxes, fields=None):
     for n in names:
         out._fields[n] = np.concatenate([b.get_field(n) for b in boxes])
     return out
+
+
+def iou(a, b):
+    """Pairwise intersection-over-union of two box lists -> (len(a), len(b)) float array
+    (stand-in for ``bbx.iou``, reference samples.py:133; areas are (x2-x1)*(y2-y1))."""
+    A = np.asarray(a.get(), np.float64).reshape(-1, 4)
+    B = np.asarray(b.get(), np.float64).reshape(-1, 4)
+    iw = np.clip(np.minimum(A[:, None, 2], B[None, :, 2]) - np.maximum(A[:, None, 0], B[None, :, 0]), 0, None)
+    ih = np.clip(np.minimum(A[:, None, 3], B[None, :, 3]) - np.maximum(A[:, None, 1], B[None, :, 1]), 0, None)
+    inter = iw * ih
+    area_a = ((A[:, 2] - A[:, 0]) * (A[:, 3] - A[:, 1]))[:, None]
+    area_b = ((B[:, 2] - B[:, 0]) * (B[:, 3] - B[:, 1]))[None, :]
+    union = area_a + area_b - inter
+    return np.where(union > 0, inter / np.where(union > 0, union, 1), 0.0)

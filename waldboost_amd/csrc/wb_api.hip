@@ -135,26 +135,23 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         return WB_ERR_UNSUPPORTED;
     }
     M->stage_dwords = WB_STAGE_DWORDS(D);
-    if (generic) {
-        // one thread per window, 4 x 64 windows per workgroup, features gathered from HBM/L2
-        M->rpw = 1;
-        M->waves = 4;
-        M->tile_rows = 4;
-        M->lds_rows = M->lds_pitch = 0;
-        M->lds_bytes = 0;
-        const int n_nodes = node_off[n_stages];
+    // the reference's own flat node arrays: walked by the generic cascade kernel and by the
+    // per-sample cascade (wb_samples_predict_launch), so every model carries them (a few KiB)
+    {
+        const int n_nodes = n_stages ? node_off[n_stages] : 0;
         std::vector<int32_t> feat((size_t)n_nodes), lft((size_t)n_nodes), rgt((size_t)n_nodes);
         for (int i = 0; i < n_nodes; ++i) {
             feat[i] = feature[i * 3] | (feature[i * 3 + 1] << 8) | (feature[i * 3 + 2] << 16);
             lft[i] = left[i];
             rgt[i] = right[i];
         }
+        const int32_t zero = 0;
         hipError_t e = hipSuccess;
         auto up = [&](void **dst, const void *src, size_t bytes) {
             if (e == hipSuccess) e = hipMalloc(dst, bytes ? bytes : 4);
             if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
         };
-        up((void **)&M->g_node_off, node_off, (size_t)(n_stages + 1) * 4);
+        up((void **)&M->g_node_off, n_stages ? node_off : &zero, (size_t)(n_stages + 1) * 4);
         up((void **)&M->g_feat, feat.data(), (size_t)n_nodes * 4);
         up((void **)&M->g_thr, threshold, (size_t)n_nodes * 4);
         up((void **)&M->g_left, lft.data(), (size_t)n_nodes * 4);
@@ -166,6 +163,14 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
             wb_model_destroy(M);
             return WB_ERR_HIP;
         }
+    }
+    if (generic) {
+        // one thread per window, 4 x 64 windows per workgroup, features gathered from HBM/L2
+        M->rpw = 1;
+        M->waves = 4;
+        M->tile_rows = 4;
+        M->lds_rows = M->lds_pitch = 0;
+        M->lds_bytes = 0;
         *out = M;
         return WB_OK;
     }
@@ -189,15 +194,13 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         if (e == hipSuccess) e = hipMemcpy(M->stages_dev, packed.data(), packed.size() * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             wb_set_error("wb_model_create: uploading %zu stage bytes failed: %s", packed.size() * 4, hipGetErrorString(e));
-            if (M->stages_dev) (void)hipFree(M->stages_dev);
-            delete M;
+            wb_model_destroy(M);
             return WB_ERR_HIP;
         }
     }
     int rc = wb_cascade_prepare(D, M->rpw, M->waves);
     if (rc != WB_OK) {
-        if (M->stages_dev) (void)hipFree(M->stages_dev);
-        delete M;
+        wb_model_destroy(M);
         return rc;
     }
     *out = M;

@@ -640,6 +640,72 @@ __global__ void tree_eval_kernel(const void *Xv, int x_u8, int u, int v, int C, 
     out[i] = prediction[node];
 }
 
+// -------------------------------------------------------------------------------------------
+// Training-time callers of the hot path (reference samples.py:14-43, model.py:181-214, training.py:73-83)
+
+// gather_samples: one wave per sample copies its m x n x C crop, row by row (a crop row is n*C
+// contiguous elements in X); VEC = elements moved per lane and step
+template <typename E>
+__global__ __launch_bounds__(64) void gather_samples_kernel(const E *X, int v, int rowlen, const int32_t *rs,
+                                                            const int32_t *cs, int m, int xstride, E *out) {
+    const int64_t i = blockIdx.x;
+    const E *src = X + ((int64_t)rs[i] * v + cs[i]) * xstride;
+    E *dst = out + i * (int64_t)m * rowlen;
+    const int total = m * rowlen;
+    for (int e = threadIdx.x; e < total; e += 64) {
+        const int y = e / rowlen, x = e - y * rowlen;
+        dst[e] = src[(int64_t)y * v * xstride + x];
+    }
+}
+
+// Model.predict on samples: one thread per sample, the reference's flat node arrays
+__global__ __launch_bounds__(256) void samples_predict_kernel(GenArgs a, int64_t n_samples, float *H, uint8_t *mask) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_samples) return;
+    const int64_t base = i * (int64_t)a.m * a.n * a.C;
+    const float *xf = reinterpret_cast<const float *>(a.chn) + base;
+    const uint8_t *x8 = reinterpret_cast<const uint8_t *>(a.chn) + base;
+    float h = 0.f;
+    bool alive = true;
+    for (int t = 0; t < a.T && alive; ++t) {
+        const int o = a.node_off[t], k = a.node_off[t + 1] - o;
+        int node = 0;
+        for (int step = 0; step < k; ++step) {
+            const int l = a.left[o + node];
+            if (l < 0) break;
+            const int f = a.feat[o + node];
+            const int at = ((f & 255) * a.n + ((f >> 8) & 255)) * a.C + ((f >> 16) & 255);
+            const float val = a.chn_u8 ? (float)x8[at] : xf[at];
+            node = (val <= a.thr[o + node]) ? l : a.right[o + node];
+        }
+        h = h + a.pred[o + node];
+        const float th = a.theta[t];
+        alive = (th == -INFINITY) || (h >= th);
+    }
+    H[i] = alive ? h : -INFINITY;
+    mask[i] = alive ? 1 : 0;
+}
+
+// DTree.apply on samples
+__global__ __launch_bounds__(256) void tree_apply_kernel(const void *Xv, int x_u8, int64_t n_samples, int m, int n, int C,
+                                                         const uint8_t *feature, const float *threshold,
+                                                         const int8_t *left, const int8_t *right, int n_nodes,
+                                                         int32_t *out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_samples) return;
+    const int64_t base = i * (int64_t)m * n * C;
+    int node = 0;
+    for (int step = 0; step < n_nodes; ++step) {
+        const int l = left[node];
+        if (l < 0) break;
+        const int at = (feature[node * 3] * n + feature[node * 3 + 1]) * C + feature[node * 3 + 2];
+        const float val = x_u8 ? (float)reinterpret_cast<const uint8_t *>(Xv)[base + at]
+                               : reinterpret_cast<const float *>(Xv)[base + at];
+        node = (val <= threshold[node]) ? l : (int)right[node];
+    }
+    out[i] = node;
+}
+
 // Model.get_boxes (reference model.py:136-147): [c, r, c+n, r+m] as fp32, times fp32(1/scale)
 __global__ void boxes_kernel(const WbDet *det, int64_t n_det, const float *inv_scale, int m, int n,
                              float *boxes, float *scores) {
@@ -781,6 +847,67 @@ extern "C" int wb_tree_eval_launch(void *stream, const void *X, int x_dtype, int
     int64_t blocks = (n_pos + 255) / 256;
     hipLaunchKernelGGL(tree_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X,
                        (int)(x_dtype == WB_DTYPE_U8), u, v, C, rs, cs, n_pos, feature, threshold, left, right, prediction, n_nodes, out);
+    WB_HIP_CHECK(hipGetLastError());
+    return WB_OK;
+}
+
+extern "C" int wb_gather_samples_launch(void *stream, const void *X, int x_dtype, int u, int v, int C,
+                                        const int32_t *rs, const int32_t *cs, int64_t n_pos, int m, int n, void *out) {
+    WB_REQUIRE(n_pos >= 0, "wb_gather_samples_launch: negative count");
+    if (n_pos == 0) return WB_OK;
+    WB_REQUIRE(X && rs && cs && out, "wb_gather_samples_launch: null pointer");
+    WB_REQUIRE(u > 0 && v > 0 && C > 0 && m > 0 && n > 0 && m <= u && n <= v, "wb_gather_samples_launch: bad shape");
+    WB_REQUIRE(x_dtype == WB_DTYPE_F32 || x_dtype == WB_DTYPE_U8, "wb_gather_samples_launch: channel dtype %d (float32 or uint8)", x_dtype);
+    WB_REQUIRE(n_pos <= 0x7fffffff, "wb_gather_samples_launch: too many samples for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)n_pos);
+    const int esz = x_dtype == WB_DTYPE_U8 ? 1 : 4;
+    const size_t px = (size_t)C * esz;                       // bytes per pixel
+    const bool al16 = px % 16 == 0 && (reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) % 16 == 0;
+    const bool al4 = px % 4 == 0 && (reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) % 4 == 0;
+    if (al16)       // whole pixels as 16-byte vectors (float32 x 4 channels: one per pixel)
+        hipLaunchKernelGGL((gather_samples_kernel<uint4>), grid, dim3(64), 0, st, (const uint4 *)X, v, n * (int)(px / 16), rs, cs, m,
+                           (int)(px / 16), (uint4 *)out);
+    else if (al4)
+        hipLaunchKernelGGL((gather_samples_kernel<uint32_t>), grid, dim3(64), 0, st, (const uint32_t *)X, v, n * (int)(px / 4), rs, cs,
+                           m, (int)(px / 4), (uint32_t *)out);
+    else
+        hipLaunchKernelGGL((gather_samples_kernel<uint8_t>), grid, dim3(64), 0, st, (const uint8_t *)X, v, n * (int)px, rs, cs, m,
+                           (int)px, (uint8_t *)out);
+    WB_HIP_CHECK(hipGetLastError());
+    return WB_OK;
+}
+
+extern "C" int wb_samples_predict_launch(void *stream, const WbModel *model, const void *X, int x_dtype,
+                                         int64_t n_samples, float *H, uint8_t *mask) {
+    WB_REQUIRE(n_samples >= 0, "wb_samples_predict_launch: negative count");
+    if (n_samples == 0) return WB_OK;
+    WB_REQUIRE(model && X && H && mask, "wb_samples_predict_launch: null pointer");
+    WB_REQUIRE(x_dtype == WB_DTYPE_F32 || x_dtype == WB_DTYPE_U8, "wb_samples_predict_launch: sample dtype %d (float32 or uint8)", x_dtype);
+    GenArgs g = {};
+    g.chn = X; g.chn_u8 = x_dtype == WB_DTYPE_U8;
+    g.T = model->n_stages; g.m = model->m; g.n = model->n; g.C = model->C;
+    g.node_off = model->g_node_off; g.feat = model->g_feat; g.left = model->g_left; g.right = model->g_right;
+    g.thr = model->g_thr; g.pred = model->g_pred; g.theta = model->g_theta;
+    const int64_t blocks = (n_samples + 255) / 256;
+    WB_REQUIRE(blocks <= 0x7fffffff, "wb_samples_predict_launch: too many samples for one launch");
+    hipLaunchKernelGGL(samples_predict_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n_samples, H, mask);
+    WB_HIP_CHECK(hipGetLastError());
+    return WB_OK;
+}
+
+extern "C" int wb_tree_apply_launch(void *stream, const void *X, int x_dtype, int64_t n_samples, int m, int n, int C,
+                                    const uint8_t *feature, const float *threshold, const int8_t *left,
+                                    const int8_t *right, int n_nodes, int32_t *node) {
+    WB_REQUIRE(n_samples >= 0, "wb_tree_apply_launch: negative count");
+    if (n_samples == 0) return WB_OK;
+    WB_REQUIRE(X && feature && threshold && left && right && node, "wb_tree_apply_launch: null pointer");
+    WB_REQUIRE(m > 0 && n > 0 && C > 0 && n_nodes > 0 && n_nodes <= 127, "wb_tree_apply_launch: bad shape");
+    WB_REQUIRE(x_dtype == WB_DTYPE_F32 || x_dtype == WB_DTYPE_U8, "wb_tree_apply_launch: sample dtype %d (float32 or uint8)", x_dtype);
+    const int64_t blocks = (n_samples + 255) / 256;
+    WB_REQUIRE(blocks <= 0x7fffffff, "wb_tree_apply_launch: too many samples for one launch");
+    hipLaunchKernelGGL(tree_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X,
+                       (int)(x_dtype == WB_DTYPE_U8), n_samples, m, n, C, feature, threshold, left, right, n_nodes, node);
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;
 }

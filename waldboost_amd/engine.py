@@ -322,6 +322,13 @@ class PyramidEngine:
                                                nat.ptr(boxes), nat.ptr(scores)), "wb_boxes_launch")
         return boxes, scores
 
+    def level_tensor(self, b, l):
+        """Channels of level l of image b as a device view [u,v,C] into the pyramid buffer."""
+        lv = self.plan.levels[l]
+        off = int(self.level_np[l]["chn_off"])
+        u, v, C = lv["u"], lv["v"], self.spec.n_channels
+        return self.chn[b, off:off + u * v * C].view(u, v, C)
+
     def read_level(self, b, l):
         """Channels of level l of image b as a fresh HWC ndarray [u,v,C] of the channel function's dtype."""
         lv = self.plan.levels[l]

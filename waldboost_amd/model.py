@@ -219,7 +219,25 @@ class Model:
                     scales=list(eng.plan.scales))
 
     def predict(self, X):
-        raise NotImplementedError("Model.predict (per-sample mode used by training) is outside the detection hot path")
+        """The cascade on samples X[N, m, n, C] -> (H, mask): H[i] is the response accumulated in stage
+        order while sample i is alive and -inf once a stage rejected it, mask[i] whether it passed
+        every stage (reference model.py:181-214; the training pool re-scores its samples with it)."""
+        import torch
+        n, *shape = X.shape
+        assert tuple(shape) == tuple(self.shape), f"Invalid shape of X. Expected {self.shape}, given {shape}"
+        xdt = _channel_dtype(X)
+        if n == 0:
+            return np.zeros(0, np.float32), np.ones(0, bool)
+        dm = self.device_cascade()
+        dev = nat.require_gpu()
+        tdt, wdt = (torch.uint8, nat.WB_DTYPE_U8) if xdt == np.uint8 else (torch.float32, nat.WB_DTYPE_F32)
+        Xd = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X))
+        Xd = Xd.to(dev, tdt).contiguous()
+        H = torch.empty(n, dtype=torch.float32, device=dev)
+        mask = torch.empty(n, dtype=torch.uint8, device=dev)
+        nat.check(nat.load().wb_samples_predict_launch(nat.stream_ptr(), dm.handle, nat.ptr(Xd), wdt, n, nat.ptr(H),
+                                                       nat.ptr(mask)), "wb_samples_predict_launch")
+        return H.cpu().numpy(), mask.cpu().numpy().astype(bool)
 
     # ---- wire format (reference model.py:285-344)
     def as_proto(self, proto):

@@ -88,10 +88,32 @@ class DTree:
         return out.cpu().numpy()
 
     def apply(self, X):
-        raise NotImplementedError("DTree.apply (per-sample mode, training only) is outside the detection hot path")
+        """Index of the leaf each sample X[i] (shape (m,n,C)) reaches (reference training.py:73-81)."""
+        import torch
+        lib = nat.load()
+        dev = nat.require_gpu()
+        N, m, n, C = X.shape
+        if N == 0:
+            return np.zeros(0, "i")
+        xdt = str(getattr(X, "dtype", None)).replace("torch.", "")
+        if xdt not in ("float32", "uint8"):
+            raise TypeError(f"samples must be float32 or uint8 (as produced by channel_pyramid), got {xdt}")
+        fmax = self.feature[self.node].max(axis=0) if self.node.any() else np.zeros(3, np.int64)
+        if int(fmax[0]) >= m or int(fmax[1]) >= n or int(fmax[2]) >= C:
+            raise IndexError("tree feature outside the sample")
+        np_dt, t_dt = (np.uint8, torch.uint8) if xdt == "uint8" else (np.float32, torch.float32)
+        wb_dt = nat.WB_DTYPE_U8 if xdt == "uint8" else nat.WB_DTYPE_F32
+        Xd = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X, np_dt))
+        Xd = Xd.to(dev, t_dt).contiguous()
+        out = torch.empty(N, dtype=torch.int32, device=dev)
+        f, t, l, r, p = self._device_arrays(dev)
+        nat.check(lib.wb_tree_apply_launch(nat.stream_ptr(), nat.ptr(Xd), wb_dt, N, m, n, C, nat.ptr(f), nat.ptr(t),
+                                           nat.ptr(l), nat.ptr(r), self.left.size, nat.ptr(out)), "wb_tree_apply_launch")
+        return out.cpu().numpy().astype("i")
 
     def predict(self, X):
-        raise NotImplementedError("DTree.predict (per-sample mode, training only) is outside the detection hot path")
+        """prediction[apply(X)] (reference training.py:82-83)."""
+        return self.prediction[self.apply(X)]
 
     def depth(self):
         def d(n):
