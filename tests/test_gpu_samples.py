@@ -115,3 +115,14 @@ def test_label_boxes_without_groundtruth():
     label_boxes(bx, None)
     assert np.array_equal(bx.get_field("tp_label"), [SampleLabel.FALSE_POSITIVE] * 2)
     assert np.array_equal(bx.get_field("instance_id"), [-1, -1])
+
+
+def test_detect_on_images_yields_the_detect_result():
+    M = wb.load(os.path.join(GOLDEN, "mixed_d2_T24.pb"))
+    g = np.load(os.path.join(GOLDEN, "mixed_200x264.npz"))
+    gt = wb.Boxes(np.array([[10, 10, 50, 50]], "f"))
+    out = list(wb.testing.detect_on_images([dict(image=g["image"], groundtruth_boxes=gt), dict(image=g["image"])], M))
+    assert len(out) == 2 and out[0][0] is gt and len(out[1][0]) == 0 and out[0][2] == (200, 264)
+    for _, dt, _ in out:
+        assert np.array_equal(dt.get_field("scores"), g["det"]["score"]) and (dt.get_field("label") == 0).all()
+    assert wb.SamplePool is SamplePool

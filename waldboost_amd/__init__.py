@@ -5,9 +5,10 @@ Keeps the reference surface for that path (reference waldboost/__init__.py:50-72
 All compute runs in hand-written HIP kernels (csrc/) through the C ABI in
 include/waldboost_hip.h; there is no CPU fallback.
 """
-from . import channels, fpga, model_pb2, samples
+from . import channels, fpga, model_pb2, samples, testing
 from .boxes import Boxes, concatenate
 from .model import Model
+from .samples import SamplePool
 from .training import DTree
 
 __version__ = "0.1.0"
@@ -67,5 +68,5 @@ def detect(image, *models, channel_opts=None, response_scale=None):
 
 default_channel_opts = dict(shrink=2, n_per_oct=8, smooth=1, channels=channels.grad_hist)
 
-__all__ = ["Model", "DTree", "Boxes", "concatenate", "channels", "fpga", "samples", "detect", "load", "load_model", "save", "save_model",
+__all__ = ["Model", "DTree", "Boxes", "concatenate", "SamplePool", "channels", "fpga", "samples", "testing", "detect", "load", "load_model", "save", "save_model",
            "default_channel_opts"]

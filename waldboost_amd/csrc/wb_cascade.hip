@@ -284,6 +284,8 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         base[j] = ((wr + j) * pitch + lane) * 4;
     }
     const int tA = T < S0 ? T : S0;
+    static_assert(S0 <= 64, "one lane per phase-A stage");
+    uint32_t entered = 0;                 // windows of this wave entering stage `lane` (phase A)
     for (int t = 0; t < tA; t += G) {
         Stage<D> st[G];
         const int32_t *sp = stages + (size_t)__builtin_amdgcn_readfirstlane(t) * SD;
@@ -300,15 +302,18 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
             int cnt = 0;
 #pragma unroll
             for (int j = 0; j < RPW; ++j) cnt += __popcll(lm[j]);
-            if (cnt && lane == 0) atomicAdd(&hist[t + g], (uint32_t)cnt);
-            const bool rejects = st[g].theta != -INFINITY;
+            entered = lane == t + g ? (uint32_t)cnt : entered;   // lane t keeps stage t's count: one LDS atomic per wave after the phase
+            // theta == -inf never rejects (a NaN sum would fail `>=`): folded into the mask, not a branch,
+            // so the RPW rows stay in one basic block and share the stage's constants in registers
+            const unsigned long long never = st[g].theta != -INFINITY ? 0ull : ~0ull;
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
                 hs[j] = hs[j] + p[g][j];                      // (a dead window's sum is never read again)
-                if (rejects) lm[j] &= __ballot(hs[j] >= st[g].theta);
+                lm[j] &= __ballot(hs[j] >= st[g].theta) | never;
             }
         }
     }
+    if (entered) atomicAdd(&hist[lane], entered);
     if (a.dbg & 4) return;
 
     // ---- survivors of phase A.  If more stages follow, the survivors of the whole workgroup are
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
                         int cnt = __popcll(am);
                         if (cnt && lane == 0) atomicAdd(&hist[t + g], (uint32_t)cnt);
                         h = h + p[g];                        // (a dead window's sum is never read again)
-                        if (st[g].theta != -INFINITY) am &= __ballot(h >= st[g].theta);
+                        am &= __ballot(h >= st[g].theta) | (st[g].theta != -INFINITY ? 0ull : ~0ull);
                     }
                 }
                 int cnt = __popcll(am);
