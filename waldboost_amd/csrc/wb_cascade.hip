@@ -371,7 +371,9 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
             // few windows left: the stage-parallel tail is cheaper than walking groups of G
             if ((t_begin >= 32 && n_q <= SPAR_MAX) || (t_begin >= SPAR_FROM && n_q <= 2)) break;
             int t_end = 2 * t_begin < t_stop ? 2 * t_begin : t_stop;
+            t_end = t_end < t_begin + 64 ? t_end : t_begin + 64;          // one counter lane per stage of the segment
             int n_out = 0;
+            uint32_t entered_b = 0;       // windows entering stage t_begin + lane, over all chunks: one LDS atomic per segment
             for (int qb = 0; qb < n_q; qb += 64) {
                 int i = qb + lane;
                 const bool mine = i < n_q;
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
                     for (int g = 0; g < G; ++g) {
                         if (t + g >= t_end) break;
                         int cnt = __popcll(am);
-                        if (cnt && lane == 0) atomicAdd(&hist[t + g], (uint32_t)cnt);
+                        entered_b += lane == t + g - t_begin ? (uint32_t)cnt : 0u;
                         h = h + p[g];                        // (a dead window's sum is never read again)
                         am &= __ballot(h >= st[g].theta) | (st[g].theta != -INFINITY ? 0ull : ~0ull);
                     }
@@ -405,6 +407,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
                     n_out += cnt;
                 }
             }
+            if (entered_b) atomicAdd(&hist[t_begin + lane], entered_b);
             n_q = n_out;
             t_begin = t_end;
         }
