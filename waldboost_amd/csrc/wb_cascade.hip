@@ -454,12 +454,16 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
             // (ripple through the wave with DPP wave_shr:1 -- lane k takes lane k-1's running sum
             // and adds its own p; after step k+1 lane k is final and later steps recompute the
             // same value, so 64 steps settle every lane)
+            // Lane 0 folds the incoming score into its addend (0 + x == x exactly), so the shifted-in
+            // value of the out-of-range lane can be the DPP zero (bound_ctrl) and each step is ONE
+            // v_add_f32 with a wave_shr:1 source.
             const float h_in = __uint_as_float(e.y);
-            float hk = h_in;
+            const float pk = lane == 0 ? h_in + p : p;
+            float hk = pk;
 #pragma unroll
-            for (int j = 0; j < 64; ++j) {
-                int prev = __builtin_amdgcn_update_dpp(__float_as_int(h_in), __float_as_int(hk), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                hk = __int_as_float(prev) + p;
+            for (int j = 0; j < 63; ++j) {
+                int prev = __builtin_amdgcn_update_dpp(0, __float_as_int(hk), 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+                hk = __int_as_float(prev) + pk;
             }
             const bool rej = (lane < nvalid) && (st.theta != -INFINITY) && !(hk >= st.theta);
             const unsigned long long rmask = __ballot(rej);
