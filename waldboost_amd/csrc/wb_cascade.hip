@@ -55,6 +55,7 @@ struct CascArgs {
     uint32_t *alive;            // [batch][n_levels][T] written by the reduction kernel
     const int32_t *tile_csr;    // [n_levels + 1] starts, then [n_tiles] tile indices grouped by level
     int n_tiles;
+    int spar[4];                // stage-parallel tail entry: (t >= spar[0] && n <= spar[1]) || (t >= spar[2] && n <= spar[3])
     int dbg;                    // diagnostics (WB_CASC_DBG): 1 = skip the tile load, 2 = stop after the load
 };
 
@@ -155,7 +156,6 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     constexpr int SD = WB_STAGE_DWORDS(D);
     constexpr int G = GroupSize<D>::G;
     constexpr int S0 = 8;                                  // stages in phase A (multiple of G; 4 and 12 measured slower)
-    constexpr int SPAR_FROM = 16, SPAR_MAX = 8;            // when a wave flips to the stage-parallel tail (see run_segments)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const WbTile tile_d = a.tiles[blockIdx.x];
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     auto run_segments = [&](int t_stop) {
         while (t_begin < t_stop && n_q > 0) {
             // few windows left: the stage-parallel tail is cheaper than walking groups of G
-            if ((t_begin >= 32 && n_q <= SPAR_MAX) || (t_begin >= SPAR_FROM && n_q <= 2)) break;
+            if ((t_begin >= a.spar[0] && n_q <= a.spar[1]) || (t_begin >= a.spar[2] && n_q <= a.spar[3])) break;
             int t_end = 2 * t_begin < t_stop ? 2 * t_begin : t_stop;
             t_end = t_end < t_begin + 64 ? t_end : t_begin + 64;          // one counter lane per stage of the segment
             int n_out = 0;
@@ -818,6 +818,9 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
     a.n_tiles = n_tiles;
     static const int dbg = getenv("WB_CASC_DBG") ? atoi(getenv("WB_CASC_DBG")) : 0;
     a.dbg = dbg;
+    // a wave flips to the stage-parallel tail when few windows are left (measured flat around these)
+    a.spar[0] = 32; a.spar[1] = 8; a.spar[2] = 16; a.spar[3] = 2;
+    if (const char *e = getenv("WB_CASC_SPAR")) sscanf(e, "%d,%d,%d,%d", &a.spar[0], &a.spar[1], &a.spar[2], &a.spar[3]);
     dim3 grid((unsigned)n_tiles, (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;
     if (model->generic) {
