@@ -113,6 +113,14 @@ struct F4 {
     float x, y, z, w;
 };
 
+// Opaque to the optimiser: stops the SLP vectoriser from pairing neighbouring scalar fp32 operations into
+// v_pk_* instructions -- on gfx950 a packed op issues in 4 cycles against 2 for each scalar op, and building
+// its operand pairs costs extra v_movs (tools/valu_rate_probe.hip)
+__device__ inline float scalar_only(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // reference channels.py:78-83: nine-term sum in source order; numba promotes int64*float32 to
 // fp64, so the sum is fp64; "/16" and one rounding to fp32 on the store.
 // 2*x and 4*x are exact, so fma(2, b, acc) rounds exactly like acc + 2*b: same bits, half the ops.
@@ -467,19 +475,19 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
 #pragma unroll
         for (int y = 0; y < S; ++y)
 #pragma unroll
-            for (int x = 0; x < P; ++x) hc[y][x] = Src<T>::hpass(pt[y][x], pt[y + 1][x], pt[y + 2][x]);
+            for (int x = 0; x < P; ++x) hc[y][x] = scalar_only(Src<T>::hpass(pt[y][x], pt[y + 1][x], pt[y + 2][x]));
 #pragma unroll
         for (int y = 0; y < P; ++y)
 #pragma unroll
-            for (int x = 0; x < S; ++x) hr[y][x] = Src<T>::hpass(pt[y][x], pt[y][x + 1], pt[y][x + 2]);
+            for (int x = 0; x < S; ++x) hr[y][x] = scalar_only(Src<T>::hpass(pt[y][x], pt[y][x + 1], pt[y][x + 2]));
 
         float ch[S][S][4];
 #pragma unroll
         for (int y = 0; y < S; ++y)
 #pragma unroll
             for (int x = 0; x < S; ++x) {
-                float gx = Src<T>::dpass(hc[y][x], hc[y][x + 2]);
-                float gy = Src<T>::dpass(hr[y][x], hr[y + 2][x]);
+                float gx = scalar_only(Src<T>::dpass(hc[y][x], hc[y][x + 2]));
+                float gy = scalar_only(Src<T>::dpass(hr[y][x], hr[y + 2][x]));
                 if constexpr (FAST)
                     project_int(gx, gy, a, ch[y][x]);
                 else
