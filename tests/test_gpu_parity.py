@@ -99,6 +99,32 @@ def test_clean_edges_hit_the_projection_leftovers():
         assert tiny > 0, "the image no longer produces leftover values"
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_low_entropy_images_mix_residues_and_ordinary_values(seed):
+    """Two-level images made of small random blocks, stripes and diagonals: gy == 0 / gx == +-gy hold for
+    a large share of the pixels, in every mixture with ordinary gradients inside the 2x2 (4x4) shrink
+    blocks -- the cases the channel kernel's two-pass projection must tell apart."""
+    rng = np.random.default_rng(seed)
+    H, W = 96 + 8 * seed, 136
+    y, x = np.mgrid[0:H, 0:W]
+    bs = int(rng.integers(2, 6))
+    blocks = np.kron(rng.integers(0, 2, (H // bs + 1, W // bs + 1)), np.ones((bs, bs), np.int64))[:H, :W]
+    diag = ((x + (1 if seed % 2 else -1) * y) // int(rng.integers(3, 9))) % 2
+    stripes = (x // int(rng.integers(2, 7))) % 2
+    pick = rng.integers(0, 3, (H // 16 + 1, W // 16 + 1))
+    pick = np.kron(pick, np.ones((16, 16), np.int64))[:H, :W]
+    img = (np.choose(pick, [blocks, diag, stripes]) * int(rng.integers(40, 255))).astype(np.uint8)
+    total_tiny = 0
+    for o in (dict(shrink=2, n_per_oct=4, smooth=1), dict(shrink=4, n_per_oct=2, smooth=0), dict(shrink=1, n_per_oct=2, smooth=1)):
+        got = list(wb.channels.channel_pyramid(img, dict(o, channels=wb.channels.grad_hist)))
+        ref = list(orc.channel_pyramid(img, dict(o, channels=orc.grad_hist)))
+        assert len(got) == len(ref) > 0
+        for (c, s), (rc, rs) in zip(got, ref):
+            assert s == rs and np.array_equal(bits(c), bits(rc))
+            total_tiny += int(((rc > 0) & (rc < 1e-6)).sum())
+    assert total_tiny > 0
+
+
 def test_shrink4_extension_vs_oracle():
     img = synth_image(200, 300, 5)
     o = dict(shrink=4, n_per_oct=3, smooth=1)

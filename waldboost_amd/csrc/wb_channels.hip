@@ -168,6 +168,20 @@ __device__ inline void project_int(float gx, float gy, const ChanArgs &a, float 
     out[3] = d3 == 0.0f ? tiny : o3;
 }
 
+// project_int without the residues: the four channel values wherever they are "ordinary" (an integer or
+// fp32(d*sin(pi/4)) >= 0.7071), and exactly 0 where the reference leaves a ~1e-13 residue (or a true 0).
+// Under the 2x2 shrink a residue only shows in the result if every pixel of the block has one (or 0) in
+// that channel: fp32 absorbs anything below 3.5e-13 into a value >= 0.7071, in any position of
+// ((a+b)+c)+d.  So the shrink is first formed from these values, and only a block whose pooled value
+// comes out 0 although it contains a gradient is redone with project_int (channels_kernel, step 2).
+__device__ inline void project_ordinary(float gx, float gy, const ChanArgs &a, float *out) {
+    const float d1 = fabsf(gx - gy), d3 = fabsf(gx + gy);
+    out[0] = fabsf(gx);
+    out[1] = __builtin_fmaf(d1, a.chi, d1 * a.clo);
+    out[2] = fabsf(gy);
+    out[3] = __builtin_fmaf(d3, a.chi, d3 * a.clo);
+}
+
 // Tile geometry shared by the channel kernels: TU x TV outputs per workgroup, shrink S
 template <int S_, int TU_, int TV_, bool SMOOTH_> struct TileGeom {
     static constexpr int S = S_, TU = TU_, TV = TV_;
@@ -481,46 +495,69 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
 #pragma unroll
             for (int x = 0; x < S; ++x) hr[y][x] = scalar_only(Src<T>::hpass(pt[y][x], pt[y][x + 1], pt[y][x + 2]));
 
-        float ch[S][S][4];
+        float ch[S][S][4], gxs[S][S], gys[S][S];
+        constexpr bool TWO_PASS = FAST && S > 1;          // ordinary values first, residues only where they can show
 #pragma unroll
         for (int y = 0; y < S; ++y)
 #pragma unroll
             for (int x = 0; x < S; ++x) {
-                float gx = scalar_only(Src<T>::dpass(hc[y][x], hc[y][x + 2]));
-                float gy = scalar_only(Src<T>::dpass(hr[y][x], hr[y + 2][x]));
-                if constexpr (FAST)
+                const float gx = scalar_only(Src<T>::dpass(hc[y][x], hc[y][x + 2]));
+                const float gy = scalar_only(Src<T>::dpass(hr[y][x], hr[y + 2][x]));
+                gxs[y][x] = gx;
+                gys[y][x] = gy;
+                if constexpr (TWO_PASS)
+                    project_ordinary(gx, gy, a, ch[y][x]);
+                else if constexpr (FAST)
                     project_int(gx, gy, a, ch[y][x]);
                 else
                     project_f64(gx, gy, a, ch[y][x]);
             }
 
         float o[4];
+        auto pool = [&]() {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if constexpr (S == 1) {
-                o[k] = ch[0][0][k];
-            } else if constexpr (S == 2) {
-                o[k] = (((ch[0][0][k] + ch[1][0][k]) + ch[0][1][k]) + ch[1][1][k]) * 0.25f;
-            } else {  // S == 4 (extension): avg_pool_2 applied twice
-                float q[2][2];
+            for (int k = 0; k < 4; ++k) {
+                if constexpr (S == 1) {
+                    o[k] = ch[0][0][k];
+                } else if constexpr (S == 2) {
+                    o[k] = (((ch[0][0][k] + ch[1][0][k]) + ch[0][1][k]) + ch[1][1][k]) * 0.25f;
+                } else {  // S == 4 (extension): avg_pool_2 applied twice
+                    float q[2][2];
 #pragma unroll
-                for (int A = 0; A < 2; ++A)
+                    for (int A = 0; A < 2; ++A)
 #pragma unroll
-                    for (int B = 0; B < 2; ++B)
-                        q[A][B] = (((ch[2 * A][2 * B][k] + ch[2 * A + 1][2 * B][k]) + ch[2 * A][2 * B + 1][k]) +
-                                   ch[2 * A + 1][2 * B + 1][k]) * 0.25f;
-                o[k] = (((q[0][0] + q[1][0]) + q[0][1]) + q[1][1]) * 0.25f;
+                        for (int B = 0; B < 2; ++B)
+                            q[A][B] = (((ch[2 * A][2 * B][k] + ch[2 * A + 1][2 * B][k]) + ch[2 * A][2 * B + 1][k]) +
+                                       ch[2 * A + 1][2 * B + 1][k]) * 0.25f;
+                    o[k] = (((q[0][0] + q[1][0]) + q[0][1]) + q[1][1]) * 0.25f;
+                }
             }
-        }
-        Sh[p] = F4{o[0], o[1], o[2], o[3]};
-        if constexpr (SEPARABLE) {
-            // integer gradients: a shrunk value is 0, or in [0.17, 1443] (some pixel of the block had a
-            // gradient), or a sum of the 1e-13-sized leftovers of the projection -- flag the last kind
+        };
+        // integer gradients: a shrunk value is 0, or in [0.17, 1443] (some pixel of the block had an
+        // ordinary value), or a sum of the 1e-13-sized residues of the projection -- the smooth wants to
+        // know about the last kind (step 3)
+        auto flag_odd = [&]() {
             const uint32_t lo = __float_as_uint(0.125f) - 1u;
             const uint32_t m01 = min(__float_as_uint(o[0]) - 1u, __float_as_uint(o[1]) - 1u);
             const uint32_t m23 = min(__float_as_uint(o[2]) - 1u, __float_as_uint(o[3]) - 1u);
             if (min(m01, m23) < lo) odd_values = 1;
+        };
+        pool();
+        if constexpr (TWO_PASS) {
+            // a pooled 0 in a block that has a gradient (pooled |gx| != 0): every pixel of the block holds a
+            // residue or 0 in that channel -- rare; redo the block with the exact values
+            if (o[0] != 0.0f && fminf(fminf(o[1], o[2]), o[3]) == 0.0f) {
+#pragma unroll
+                for (int y = 0; y < S; ++y)
+#pragma unroll
+                    for (int x = 0; x < S; ++x) project_int(gxs[y][x], gys[y][x], a, ch[y][x]);
+                pool();
+                if constexpr (SEPARABLE) flag_odd();
+            }
+        } else if constexpr (SEPARABLE) {
+            flag_odd();
         }
+        Sh[p] = F4{o[0], o[1], o[2], o[3]};
     }
     __syncthreads();
     WB_CSTAMP(5);
