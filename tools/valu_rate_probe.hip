@@ -21,12 +21,25 @@ template <int OP> __global__ void k(float *out, int iters) {
             if (OP == 9) asm volatile("v_cmp_le_f32 vcc, %0, %1" : : "v"(a), "v"(b) : "vcc");
             if (OP == 10) asm volatile("v_add_u32 %0, %1, %1" : "=v"(u) : "v"(u));
             if (OP == 11) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x) : "v"(y));
+            if (OP == 12) asm volatile("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(u) : "v"(u));
+            if (OP == 13) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(a) : "v"(u));
+            if (OP == 14) asm volatile("v_floor_f32 %0, %1" : "=v"(a) : "v"(b));
+            if (OP == 15) asm volatile("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(b), "v"(c));
+            if (OP == 16) asm volatile("v_min3_u32 %0, %1, %1, %1" : "=v"(u) : "v"(u));
+            if (OP == 17) asm volatile("v_fract_f32 %0, %1" : "=v"(a) : "v"(b));
+            if (OP == 18) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a) : "v"(b), "v"(c));
+            if (OP == 19) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a) : "v"(b), "v"(c));
+            if (OP == 20) asm volatile("v_lshl_add_u32 %0, %1, 2, %1" : "=v"(u) : "v"(u));
+            if (OP == 21) asm volatile("v_and_b32 %0, %1, %1" : "=v"(u) : "v"(u));
+            if (OP == 22) asm volatile("v_mul_u32_u24 %0, %1, %1" : "=v"(u) : "v"(u));
+            if (OP == 23) asm volatile("v_readlane_b32 s20, %0, 3" : : "v"(u) : "s20");
+            if (OP == 24) asm volatile("v_mul_hi_u32 %0, %1, %1" : "=v"(u) : "v"(u));
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a + d + (float)x + (float)u;
 }
 template <int OP> void run(const char *name, float *out) {
-    for (int wps : {1, 2, 4}) {           // waves per SIMD: blocks of wps*256 threads, one block per CU
+    for (int wps : {1, 4}) {           // waves per SIMD: blocks of wps*256 threads, one block per CU
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         const int iters = 2000;
         hipLaunchKernelGGL(k<OP>, dim3(256), dim3(256 * wps), 0, 0, out, 10);
@@ -43,5 +56,9 @@ int main() {
     run<0>("v_fma_f32", out); run<1>("v_pk_fma_f32", out); run<11>("v_pk_add_f32", out); run<2>("v_fma_f64", out); run<7>("v_add_f64", out);
     run<3>("v_cvt_f32_ubyte0", out); run<5>("v_cvt_f64_f32", out); run<4>("v_cndmask_b32", out); run<9>("v_cmp_le_f32", out);
     run<8>("v_mov_b32", out); run<10>("v_add_u32", out); run<6>("v_mul_lo_u32", out);
+    run<12>("v_mad_u32_u24", out); run<22>("v_mul_u32_u24", out); run<24>("v_mul_hi_u32", out); run<13>("v_cvt_f32_u32", out);
+    run<14>("v_floor_f32", out); run<17>("v_fract_f32", out); run<15>("v_max_f32", out); run<18>("v_mul_f32", out);
+    run<19>("v_sub_f32", out); run<16>("v_min3_u32", out); run<20>("v_lshl_add_u32", out); run<21>("v_and_b32", out);
+    run<23>("v_readlane_b32", out);
     return 0;
 }
