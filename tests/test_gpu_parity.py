@@ -394,6 +394,42 @@ def test_detect_batch_equals_per_image_detect():
     assert [len(b) for b in bxs] == [int((res["image"] == b).sum()) for b in range(5)]
 
 
+def test_full_size_batch_properties():
+    """BASELINE configs[2] shape (a batch of 1080p images, 128-stage depth-2 cascade) through the
+    size-independent properties of the path: the batch result is the concatenation of the per-image
+    results (bit for bit), detections come sorted by (image, level, r, c), the statistics add up
+    (alive[.,.,0] = every window, non-increasing over the stages, last column >= detections), and a
+    second run reproduces the first exactly."""
+    M = wb.load(os.path.join(GOLDEN, "models", "cfg2_d2_T128.pb"))
+    B = 16
+    imgs = np.stack([synth_image(1080, 1920, 1000 + b) for b in range(B)])
+    res = M.detect_batch_raw(imgs)
+    n_loc, n_weak = M.n_loc, M.n_weak
+    assert n_loc == B * 3045278
+    key = np.stack([res["image"], res["level"], res["r"], res["c"]], 1).astype(np.int64)
+    order = np.lexsort((key[:, 3], key[:, 2], key[:, 1], key[:, 0]))
+    assert np.array_equal(order, np.arange(key.shape[0]))
+    alive = res["alive"]                                        # [B, levels, stages]
+    assert alive[:, :, 0].sum() == n_loc and alive.sum() == n_weak
+    assert (np.diff(alive, axis=2) <= 0).all()
+    # windows alive after the last stage = detections: the last stage's theta of this model is -inf or calibrated,
+    # so count them from the records
+    per_image = np.bincount(res["image"], minlength=B)
+    assert (alive[:, :, -1].sum(axis=1) >= per_image).all() and per_image.min() > 0
+    M.reset()
+    again = M.detect_batch_raw(imgs)
+    for k in ("image", "level", "r", "c"):
+        assert np.array_equal(res[k], again[k])
+    assert np.array_equal(bits(res["scores"]), bits(again["scores"])) and np.array_equal(res["alive"], again["alive"])
+    M.reset()
+    for b in (0, 7, B - 1):
+        one = M.detect_raw(imgs[b])
+        sel = res["image"] == b
+        assert np.array_equal(res["level"][sel], one["level"]) and np.array_equal(res["r"][sel], one["r"])
+        assert np.array_equal(res["c"][sel], one["c"]) and np.array_equal(bits(res["scores"][sel]), bits(one["scores"]))
+        assert np.array_equal(bits(res["boxes"][sel]), bits(one["boxes"])) and np.array_equal(res["alive"][b], one["alive"])
+
+
 def test_config5_4k_shrink4_256_stages_vs_oracle():
     """BASELINE configs[4]: 3840x2160, shrink=4 (extension: the reference asserts shrink in [1,2]),
     n_per_oct=12, 256-stage depth-2 cascade, survival ~1e-4 -- against the oracle at full size."""
