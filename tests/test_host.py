@@ -212,3 +212,63 @@ def test_uint8_projection_identity_holds_on_the_cpu_too():
             fast = (d * np.float64(chi) + lo.astype(np.float64)).astype(np.float32)      # == fmaf(d, chi, d*clo)
         slow = (GX != 0) & ((GY == 0) | (GX == GY) | (GX == -GY))
         assert np.array_equal(fast[~slow].view(np.uint32), ref[~slow].view(np.uint32)), k
+
+
+# ------------------------------------------------------------------------------ rows 8f: names, labels, pool (no GPU)
+@pytest.mark.parametrize("fn,name", [("grad_hist_4_u1", "waldboost.fpga.channels.grad_hist_4_u1"),
+                                     ("grad_mag_u1", "waldboost.fpga.channels.grad_mag_u1"),
+                                     ("grad_mag", "waldboost.channels.grad_mag")])
+def test_pb_of_the_other_channel_functions_round_trips_byte_for_byte(tmp_path, fn, name):
+    src = os.path.join(GOLDEN, f"{fn}_d2_T24.pb")               # written by the reference's own Model.save
+    M = wb.load(src)
+    spec = wb.channels.channel_spec(M.channel_opts["channels"])
+    assert spec.key == fn and spec.reference_name == name and wb.model.symbol_name(M.channel_opts["channels"]) == name
+    assert M.shape[2] == spec.n_channels
+    out = tmp_path / "m.pb"
+    M.save(str(out))
+    assert out.read_bytes() == open(src, "rb").read()
+    # our own function objects and the short aliases resolve to the same specs
+    assert wb.channels.CHANNEL_FUNCS["waldboost_amd.channels." + fn] is spec.func
+    assert wb.fpga.grad_hist_4_u1 is wb.channels.SPECS["grad_hist_4_u1"].func
+
+
+def test_iou_and_label_boxes_host_logic():
+    from waldboost_amd.boxes import iou
+    from waldboost_amd.samples import SampleLabel, label_boxes, select_candidates
+    dt = wb.Boxes(np.array([[0, 0, 10, 10], [5, 5, 15, 15], [100, 100, 110, 110], [0, 0, 9, 10]], "f"))
+    gt = wb.Boxes(np.array([[0, 0, 10, 10], [200, 200, 210, 210]], "f"), ignore=np.array([0, 1]))
+    t = iou(dt, gt)
+    assert t.shape == (4, 2) and t[0, 0] == 1.0 and abs(t[1, 0] - 25 / 175) < 1e-12 and t[2, 0] == 0 and abs(t[3, 0] - 0.9) < 1e-12
+    label_boxes(dt, gt, min_tp_iou=0.7, max_fp_iou=0.3)
+    assert list(dt.get_field("tp_label")) == [SampleLabel.TRUE_POSITIVE, SampleLabel.FALSE_POSITIVE,
+                                              SampleLabel.FALSE_POSITIVE, SampleLabel.TRUE_POSITIVE]
+    assert list(dt.get_field("instance_id")) == [0, 0, 0, 0]
+    # a detection on an ignored ground-truth box is neither TP nor FP
+    dt2 = wb.Boxes(np.array([[200, 200, 210, 210]], "f"))
+    label_boxes(dt2, gt)
+    assert list(dt2.get_field("tp_label")) == [SampleLabel.IGNORE] and list(dt2.get_field("instance_id")) == [1]
+    # candidate caps
+    np.random.seed(1)
+    many = wb.Boxes(np.tile(np.array([[300, 300, 310, 310]], "f"), (50, 1)))
+    label_boxes(many, gt, max_fp_candidates=7)
+    assert 1 <= (many.get_field("tp_label") == SampleLabel.FALSE_POSITIVE).sum() <= 7       # np.random.choice draws with replacement
+    assert select_candidates(np.array([0, 1, 1, 0, 1], bool), 10).tolist() == [1, 2, 4]
+    with pytest.raises(ValueError):
+        label_boxes(dt, wb.Boxes(np.zeros((1, 4), "f"), ignore=np.zeros((1, 1))))
+    label_boxes(None, gt)                                        # no-op, like the reference
+
+
+def test_sample_pool_bookkeeping_without_a_gpu():
+    from waldboost_amd.samples import SampleLabel, SamplePool
+    pool = SamplePool(min_tp=2, min_fp=3)
+    assert pool.pool_stats() == dict(num_tp=0, num_fp=0)
+    bx = wb.Boxes(np.zeros((4, 4), "f"), scores=np.array([1.0, -np.inf, 2.0, 0.5], "f"),
+                  tp_label=np.array([1, -1, -1, 1], np.int32), samples=np.arange(4 * 2 * 2 * 1, dtype=np.float32).reshape(4, 2, 2, 1))
+    pool.samples = bx
+    assert pool.pool_stats() == dict(num_tp=2, num_fp=2)
+    pool.remove_low_scoring()
+    assert pool.pool_stats() == dict(num_tp=2, num_fp=1)
+    X, H = pool.get_false_positives()
+    assert X.shape == (1, 2, 2, 1) and H.tolist() == [2.0]
+    X[...] = -1                                                  # copies: the pool is not touched
+    assert pool.get_samples(SampleLabel.FALSE_POSITIVE)[0].min() >= 0

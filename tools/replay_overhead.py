@@ -46,3 +46,51 @@ t0 = time.perf_counter()
 for i in range(2000): g.replay()
 t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print(f"1-kernel graph: issue {1e6 * (t1 - t0) / 2000:.1f} us, total {1e6 * (t2 - t0) / 2000:.1f} us per replay")
+
+# ---- one graph holding the P steps as parallel branches (fork/join inside the capture)
+side = [torch.cuda.Stream() for _ in range(P)]
+big = torch.cuda.CUDAGraph()
+torch.cuda.synchronize()
+with torch.cuda.graph(big):
+    cur = torch.cuda.current_stream()
+    for j in range(P):
+        side[j].wait_stream(cur)
+        with torch.cuda.stream(side[j]):
+            engines[j].run(dm)
+    for j in range(P):
+        cur.wait_stream(side[j])
+torch.cuda.synchronize()
+for rep in range(2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(N // P):
+        big.replay()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+print(f"one {P}-branch graph: total {1e6 * (t2 - t0) / N:.1f} us/step")
+# two such graphs alternating on two streams (the join of one overlaps the fork of the other)
+big2 = torch.cuda.CUDAGraph()
+engines2 = []
+for i in range(P):
+    e = PyramidEngine(1080, 1920, np.uint8, 2, 8, 1, batch=1, det_capacity=16384)
+    e.load_images(synth_image(1080, 1920, 10 + i)[None]); e.run(dm); engines2.append(e)
+torch.cuda.synchronize()
+with torch.cuda.graph(big2):
+    cur = torch.cuda.current_stream()
+    for j in range(P):
+        side[j].wait_stream(cur)
+        with torch.cuda.stream(side[j]):
+            engines2[j].run(dm)
+    for j in range(P):
+        cur.wait_stream(side[j])
+torch.cuda.synchronize()
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+for rep in range(2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(N // (2 * P)):
+        with torch.cuda.stream(sa): big.replay()
+        with torch.cuda.stream(sb): big2.replay()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+print(f"two {P}-branch graphs on two streams: total {1e6 * (t2 - t0) / N:.1f} us/step")
