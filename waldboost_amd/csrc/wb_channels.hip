@@ -837,21 +837,37 @@ __global__ __launch_bounds__(256) void channels_gm_kernel(ChanArgs a) {
     const bool ident = (L.src_h == L.nh) && (L.src_w == L.nw);
     const int ry0 = S * (u0 - HS) - NH - 1, rx0 = S * (v0 - HS) - NH - 1;
 
-    // ---- resized pixels (reference channels.py:132), reflected outside the level
-    for (int p = tid; p < RH * RW; p += 256) {
-        const int k = p / RW, q = p - k * RW;
-        const int y = reflect_index(ry0 + k, L.nh), x = reflect_index(rx0 + q, L.nw);
-        const Tap tr = rtap[y], tc = ctap[x];
-        const T *r0 = src + (int64_t)tr.i0 * L.src_w, *r1 = src + (int64_t)tr.i1 * L.src_w;
-        const T a00 = r0[tc.i0], a01 = r0[tc.i1], a10 = r1[tc.i0], a11 = r1[tc.i1];
-        float out = 0.0f;
-        bool ok = ident;
-        if (ident) out = (float)a00;
-        if constexpr (Src<T>::kFastResample)
-            if (!ok) ok = Src<T>::fast((float)a00, (float)a01, (float)a10, (float)a11, (float)tr.w0, (float)tr.w1,
-                                       (float)tc.w0, (float)tc.w1, out);
-        if (!ok) out = Src<T>::finish(resample_f64((double)a00, (double)a01, (double)a10, (double)a11, tr, tc), mn, mx);
-        R[p] = out;
+    // ---- resized pixels (reference channels.py:132), reflected outside the level.  U pixels per thread and
+    //      pass: their tap loads, then their source loads, are all in flight together (clamped indices,
+    //      unconditional loads; the store is guarded)
+    constexpr int U = 4;
+    for (int p0 = tid; p0 < RH * RW; p0 += 256 * U) {
+        Tap tr[U], tc[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            int p = p0 + 256 * k;
+            p = p < RH * RW ? p : RH * RW - 1;
+            const int kk = p / RW, q = p - kk * RW;
+            tr[k] = rtap[reflect_index(ry0 + kk, L.nh)];
+            tc[k] = ctap[reflect_index(rx0 + q, L.nw)];
+        }
+        T a00[U], a01[U], a10[U], a11[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const T *r0 = src + (int64_t)tr[k].i0 * L.src_w, *r1 = src + (int64_t)tr[k].i1 * L.src_w;
+            a00[k] = r0[tc[k].i0]; a01[k] = r0[tc[k].i1]; a10[k] = r1[tc[k].i0]; a11[k] = r1[tc[k].i1];
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            float out = 0.0f;
+            bool ok = ident;
+            if (ident) out = (float)a00[k];
+            if constexpr (Src<T>::kFastResample)
+                if (!ok) ok = Src<T>::fast((float)a00[k], (float)a01[k], (float)a10[k], (float)a11[k], (float)tr[k].w0,
+                                           (float)tr[k].w1, (float)tc[k].w0, (float)tc[k].w1, out);
+            if (!ok) out = Src<T>::finish(resample_f64((double)a00[k], (double)a01[k], (double)a10[k], (double)a11[k], tr[k], tc[k]), mn, mx);
+            if (p0 + 256 * k < RH * RW) R[p0 + 256 * k] = out;
+        }
     }
     __syncthreads();
 
