@@ -819,8 +819,13 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
     static const int dbg = getenv("WB_CASC_DBG") ? atoi(getenv("WB_CASC_DBG")) : 0;
     a.dbg = dbg;
     // a wave flips to the stage-parallel tail when few windows are left (measured flat around these)
-    a.spar[0] = 32; a.spar[1] = 8; a.spar[2] = 16; a.spar[3] = 2;
-    if (const char *e = getenv("WB_CASC_SPAR")) sscanf(e, "%d,%d,%d,%d", &a.spar[0], &a.spar[1], &a.spar[2], &a.spar[3]);
+    struct Spar { int v[4]; };
+    static const Spar spar = [] {
+        Spar s = {{32, 8, 16, 2}};
+        if (const char *e = getenv("WB_CASC_SPAR")) sscanf(e, "%d,%d,%d,%d", &s.v[0], &s.v[1], &s.v[2], &s.v[3]);
+        return s;
+    }();
+    for (int i = 0; i < 4; ++i) a.spar[i] = spar.v[i];
     dim3 grid((unsigned)n_tiles, (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;
     if (model->generic) {
