@@ -187,7 +187,8 @@ int wb_model_info(const WbModel *model, WbModelInfo *info);
 /* Dense sliding-window cascade over all levels of all images.
  *   chn           [u][v][C] per level as written by wb_channels_launch (or caller-provided), of
  *                 chn_dtype WB_DTYPE_F32 or WB_DTYPE_U8 (uint8 values compare against the float32
- *                 thresholds as their exact float32 values, like NumPy's uint8 <= float32)
+ *                 thresholds as their exact float32 values, like NumPy's uint8 <= float32); a uint8
+ *                 buffer must extend 16 bytes past its last element (16-byte group loads)
  *   tiles         dev WbTile[n_tiles]: tiles of tile_rows x tile_cols WINDOWS over the
  *                 (u-m) x (v-n) window grid of each level
  *   det           dev WbDet[WB_DET_SHARDS][shard_capacity]; det_count dev uint32[WB_DET_SHARDS]:

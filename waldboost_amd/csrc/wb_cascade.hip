@@ -183,6 +183,47 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     const float *chn = reinterpret_cast<const float *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
     const uint8_t *chn8 = reinterpret_cast<const uint8_t *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
     if (a.dbg & 1) {
+    } else if (U8 && a.C == 4 && (pitch & 3) == 0) {
+        // uint8 channels, one dword per pixel, 16 bytes = FOUR pixels per lane and load: a quarter of the
+        // float path's load instructions for a quarter of its bytes.  The 16 values are widened to their
+        // exact float32 values (uint8 <= float32 compares in float32 under NumPy promotion, so the stage
+        // loop is unchanged) and leave as one 16-byte LDS store per channel plane.  A group may read up to
+        // 12 bytes past the end of a level row (the buffers carry 16 spare bytes); those pixels land in
+        // columns no window of the level reads.
+        constexpr int U = 2;
+        const int ngrp = (WB_CASC_TC + a.n - 1 + 3) >> 2;            // 4-pixel groups per tile row (<= pitch / 4)
+        const int total = rows * ngrp;
+        const uint32_t m_ngrp = 0xFFFFFFFFu / (uint32_t)ngrp + 1u;
+        const int plane = rows * pitch;
+        struct __attribute__((aligned(4))) Px4 { uint32_t x, y, z, w; };      // four pixels, dword-aligned only
+        for (int e0 = tid; e0 < total; e0 += NT * U) {
+            Px4 v[U];
+            int dst[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                uint32_t e = (uint32_t)(e0 + k * NT);
+                e = e < (uint32_t)total ? e : (uint32_t)total - 1u;  // duplicates rewrite the same values
+                const uint32_t row = __umulhi(e, m_ngrp), grp = e - row * (uint32_t)ngrp;
+                int gr = r0 + (int)row, gc = c0 + 4 * (int)grp;
+                gr = gr < L.u ? gr : L.u - 1;
+                gc = gc < L.v ? gc : L.v - 1;
+                v[k] = *reinterpret_cast<const Px4 *>(chn8 + ((int64_t)gr * L.v + gc) * 4);
+                dst[k] = (int)(row * (uint32_t)pitch + 4u * grp);
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const uint32_t px[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    float4 f;
+                    f.x = (float)((px[0] >> (8 * ch)) & 255u);
+                    f.y = (float)((px[1] >> (8 * ch)) & 255u);
+                    f.z = (float)((px[2] >> (8 * ch)) & 255u);
+                    f.w = (float)((px[3] >> (8 * ch)) & 255u);
+                    *reinterpret_cast<float4 *>(tile + dst[k] + ch * plane) = f;
+                }
+            }
+        }
     } else if (U8 && a.C == 4) {
         // uint8 channels, one dword per pixel: same batched scheme as the float4 path below; the
         // four bytes are widened to their exact float32 values on the way into the LDS planes

@@ -169,7 +169,9 @@ class PyramidEngine:
         tiles = p.chan_tiles()
         self.n_chan_tiles = int(tiles.size)
         self.chan_tiles = torch.from_numpy(tiles.view(np.uint8).copy()).to(dev) if tiles.size else None
-        self.chn = torch.zeros((self.batch, self.chn_stride), dtype=_torch_dtype(self.spec.dtype), device=dev)
+        # (16 spare elements: the cascade's uint8 tile load fetches 16-byte groups that may run past a level row)
+        self._chn_flat = torch.zeros(self.batch * self.chn_stride + 16, dtype=_torch_dtype(self.spec.dtype), device=dev)
+        self.chn = self._chn_flat[: self.batch * self.chn_stride].view(self.batch, self.chn_stride)
         self.cs_sn = orientation_constants()
         self._oct_off = (C.c_int64 * max(p.n_oct, 1))(*[int(x) for x in p.oct_off[:max(p.n_oct, 1)]])
         self.det_capacity = int(det_capacity)

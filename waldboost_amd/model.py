@@ -325,7 +325,7 @@ class _SingleLevel:
         self.dtype = np.dtype(dtype)
         self.tdtype = torch.uint8 if self.dtype == np.uint8 else torch.float32
         self.wb_dtype = nat.WB_DTYPE_U8 if self.dtype == np.uint8 else nat.WB_DTYPE_F32
-        self.X = torch.empty((max(u * v * C, 1) + 4,), dtype=self.tdtype, device=self.dev)
+        self.X = torch.empty((max(u * v * C, 1) + 16,), dtype=self.tdtype, device=self.dev)   # + spare bytes (see wb_cascade_launch)
         self.detb = _engine.DetBuffer(1 << 10, self.dev)
         self._tiles = {}
 
