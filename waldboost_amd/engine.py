@@ -116,6 +116,15 @@ class DetBuffer:
     def max_count(self):
         return int(self.counts.max().item())
 
+    def valid_records(self, counts):
+        """The valid records of all shards (shard order) as one int32 [n, 4] tensor, given the host copy of
+        the shard counters: plain slices, no mask."""
+        import torch
+        parts = [self.recs[s * self.cap: s * self.cap + int(c)] for s, c in enumerate(counts) if c]
+        if not parts:
+            return self.recs[:0]
+        return parts[0] if len(parts) == 1 else torch.cat(parts)
+
     def compact(self):
         """All valid records as one int32 [n, 4] tensor (shard order)."""
         import torch
@@ -305,6 +314,17 @@ class PyramidEngine:
             if need <= self.detb.cap:
                 return int(self.detb.counts.sum().item())
             self.det_capacity = (int(need * 1.5) + 16) * nat.WB_DET_SHARDS
+            self._alloc_det()
+            self.run_cascade(dm)
+
+    def shard_counts(self, dm):
+        """Host copy of the shard counters after the last scan; re-runs the cascade with a larger buffer if a
+        shard overflowed."""
+        while True:
+            counts = self.detb.counts.cpu().numpy().astype(np.int64)
+            if counts.max(initial=0) <= self.detb.cap:
+                return counts
+            self.det_capacity = (int(counts.max() * 1.5) + 16) * nat.WB_DET_SHARDS
             self._alloc_det()
             self.run_cascade(dm)
 
