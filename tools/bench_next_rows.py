@@ -35,6 +35,17 @@ for key in ("grad_hist", "grad_hist_4_u1", "grad_mag_u1", "grad_mag"):
     ab = e.plan.algorithmic_bytes(1)["channels_kernel"] * B
     print(f"channels {key:15s} {ms / B * 1e3:7.1f} us/image  {ab / ms / 1e6:7.1f} GB/s algorithmic ({ab / B / 1e6:.1f} MB/image)")
 
+# float32 images (secondary input type of SURVEY 8d): fp64 resample / gradient passes / projection
+imgs_f = np.stack([synth_image(1080, 1920, s, np.float32) for s in range(B)])
+for key in ("grad_hist", "grad_mag"):
+    e = PyramidEngine(1080, 1920, np.float32, 2, 8, 1, batch=B, channels=SPECS[key])
+    e.load_images(imgs_f)
+    e.run_channels(); torch.cuda.synchronize()
+    ms = t(e.launch_channels)
+    ab = e.plan.algorithmic_bytes(4)["channels_kernel"] * B
+    oc = t(e.launch_octaves)
+    print(f"float32 image: channels {key:10s} {ms / B * 1e3:7.1f} us/image  {ab / ms / 1e6:7.1f} GB/s algorithmic; octaves {oc / B * 1e3:.1f} us/image")
+
 M = wb.load(os.path.join(ROOT, "tests/golden/models/cfg2_d2_T128.pb"))
 e = PyramidEngine(1080, 1920, np.uint8, 2, 8, 1, batch=1)
 e.load_images(imgs[:1]); e.run_channels()
