@@ -91,10 +91,10 @@ def test_u1_detect_vs_reference_fixture(fn):
     assert M.n_weak == int(g["n_weak"])
 
 
-def u1_model(fn, seed, T, depth, lo, hi, sa=-0.45, sb=-0.15):
+def u1_model(fn, seed, T, depth, lo, hi, sa=-0.45, sb=-0.15, window=(12, 12)):
     rng = np.random.default_rng(seed)
     C = 4 if fn == "grad_hist_4_u1" else 1
-    shape = (12, 12, C)
+    shape = (window[0], window[1], C)
     M = wb.Model(shape, dict(shrink=2, n_per_oct=8, smooth=1, channels=FUNCS[fn]))
     acc = 0.0
     for t in range(T):
@@ -121,6 +121,21 @@ def test_u1_detect_vs_oracle(fn, depth):
     assert np.array_equal(bits(res["scores"]), bits(ref["scores"]))
     assert np.array_equal(bits(res["boxes"]), bits(ref["boxes"]))
     assert M.n_loc == ref["n_loc"] and M.n_weak == ref["n_weak"]
+
+
+@pytest.mark.parametrize("fn", sorted(FUNCS))
+@pytest.mark.parametrize("window", [(9, 17), (10, 10), (16, 8), (20, 31)])
+def test_u1_detect_other_window_shapes(fn, window):
+    """Window widths with 64 + n not a multiple of 4 take the per-pixel uint8 tile load, the others the
+    16-byte group load; both must agree with the oracle at the right and bottom borders of every level."""
+    img = synth_image(203, 277, 23)
+    M = u1_model(fn, 3, 24, 2, 1.0, 20.0, window=window)
+    res = M.detect_raw(img)
+    ref = oracle_detect(M, img)
+    assert ref["scores"].size > 0
+    assert np.array_equal(res["alive"], ref["alive"]) and np.array_equal(res["level"], ref["level"])
+    assert np.array_equal(res["r"], ref["r"]) and np.array_equal(res["c"], ref["c"])
+    assert np.array_equal(bits(res["scores"]), bits(ref["scores"]))
 
 
 def test_u1_batch_and_tree_eval():
