@@ -239,10 +239,14 @@ def main():
         it = max(20, min(args.steps, 100))
         kern["octaves_ms"] = event_time_ms(e.launch_octaves, it, torch)
         kern["channels_ms"] = event_time_ms(e.launch_channels, it, torch)
-        kern["cascade_ms"] = event_time_ms(lambda: e.run_cascade(dm), it, torch)   # tile + deep kernels (+ counter resets)
+        kern["cascade_ms"] = event_time_ms(lambda: e.run_cascade(dm), it, torch)   # counter reset + tile kernel + statistics reduction
+        # the dominant kernel alone, as rocprofv3 sees it: cascade_tile_kernel without its follow-up reduction
+        # (the counters are not reset in this loop; records past the capacity are dropped, the work is the same)
+        kern["cascade_tile_ms"] = event_time_ms(lambda: e.launch_cascade(dm, reduce=False), it, torch)
+        e.run_cascade(dm)
         ab = plan.algorithmic_bytes(1)
-        name = "channels_kernel" if kern["channels_ms"] >= kern["cascade_ms"] else "cascade_kernel"
-        ms = kern["channels_ms"] if name == "channels_kernel" else kern["cascade_ms"]
+        name = "channels_kernel" if kern["channels_ms"] >= kern["cascade_tile_ms"] else "cascade_kernel"
+        ms = kern["channels_ms"] if name == "channels_kernel" else kern["cascade_tile_ms"]
         abytes = ab[name] * B
         # HBM bytes per launch from the committed rocprofv3 PMC passes (batch-1 launches only)
         traffic = None
@@ -252,7 +256,7 @@ def main():
                 tj = json.load(f)
             key = "channels_kernel" if name == "channels_kernel" else "cascade_tile_kernel"
             traffic = tj.get(key, {}).get("traffic_bytes_per_launch_b1")
-        roof = {"bound": "hbm", "kernel": name, "achieved": abytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+        roof = {"bound": "hbm", "kernel": "channels_kernel" if name == "channels_kernel" else "cascade_tile_kernel", "achieved": abytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": ms}
 

@@ -199,7 +199,8 @@ int wb_model_info(const WbModel *model, WbModelInfo *info);
  *   tile_hist     dev uint32 [batch][n_tiles][n_stages] scratch: per-workgroup alive counts,
  *                 fully overwritten (no zeroing needed)
  *   alive         dev uint32 [batch][n_levels][n_stages]: windows entering each stage, summed
- *                 over the level's tiles by a small follow-up kernel; overwritten
+ *                 over the level's tiles by a small follow-up kernel; overwritten.  NULL = skip that
+ *                 kernel (the per-tile counts in tile_hist are still written)
  * det_count is ACCUMULATED into: the caller zeroes it.  Record order is unspecified; sort by
  * (image, level, r, c) to obtain the reference order. */
 int wb_cascade_launch(void *stream, const WbModel *model, const void *chn, int chn_dtype,

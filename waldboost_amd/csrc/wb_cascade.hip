@@ -782,7 +782,7 @@ int launch_depth(hipStream_t st, dim3 grid, const CascArgs &a, int rpw, int wave
             hipLaunchKernelGGL((cascade_tile_kernel<D, R, W, true>), grid, dim3(W * 64), lds, st, a, a.stages);  \
         else                                                                                                \
             hipLaunchKernelGGL((cascade_tile_kernel<D, R, W, false>), grid, dim3(W * 64), lds, st, a, a.stages); \
-        if (a.T > 0)                                                                                        \
+        if (a.T > 0 && a.alive)                                                                             \
             hipLaunchKernelGGL(alive_reduce_kernel, dim3(a.n_levels, grid.y), dim3(1024),                          \
                                0, st, a.tile_hist, a.tile_csr, a.n_levels, a.n_tiles, a.T, a.alive);         \
         WB_HIP_CHECK(hipGetLastError());                                                                    \
@@ -829,7 +829,7 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
                                  const WbTile *tiles, const int32_t *tile_csr, int n_tiles, WbDet *det,
                                  uint32_t *det_count, uint32_t shard_capacity, uint32_t *tile_hist,
                                  uint32_t *alive) {
-    WB_REQUIRE(model && chn && levels && tiles && tile_csr && det_count && alive, "wb_cascade_launch: null pointer");
+    WB_REQUIRE(model && chn && levels && tiles && tile_csr && det_count, "wb_cascade_launch: null pointer");
     WB_REQUIRE(tile_hist || model->n_stages == 0, "wb_cascade_launch: tile_hist scratch is null");
     WB_REQUIRE(det || shard_capacity == 0, "wb_cascade_launch: det is null but capacity > 0");
     WB_REQUIRE(batch >= 1 && batch <= 65535, "wb_cascade_launch: batch %d out of range", batch);
@@ -880,7 +880,7 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
         size_t lds = (((size_t)g.T * 4 + 15) & ~(size_t)15) + 256 * 8;
         WB_REQUIRE(lds <= 64 * 1024, "wb_cascade_launch: %d stages exceed the generic kernel's LDS", g.T);
         hipLaunchKernelGGL(cascade_generic_kernel, grid, dim3(256), lds, st, g);
-        if (g.T > 0)
+        if (g.T > 0 && alive)
             hipLaunchKernelGGL(alive_reduce_kernel, dim3(n_levels, grid.y), dim3(1024), 0, st, tile_hist, tile_csr,
                                n_levels, n_tiles, g.T, alive);
         WB_HIP_CHECK(hipGetLastError());

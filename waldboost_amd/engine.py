@@ -263,7 +263,9 @@ class PyramidEngine:
             self._casc = {key: stt}          # one cascade resident per engine
         return stt
 
-    def launch_cascade(self, dm):
+    def launch_cascade(self, dm, reduce=True):
+        """The cascade scan; reduce=False launches the tile kernel alone (no per-level statistics), which
+        is what bench.py times for the roofline of that kernel."""
         stt = self._casc_state(dm)
         if stt["n_tiles"] == 0:
             return stt
@@ -272,7 +274,7 @@ class PyramidEngine:
                                              self.batch, nat.ptr(self.levels), self.plan.n_levels,
                                              nat.ptr(stt["tiles"]), nat.ptr(stt["csr"]), stt["n_tiles"],
                                              nat.ptr(self.detb.recs), nat.ptr(self.detb.counts), self.detb.cap,
-                                             nat.ptr(stt["tile_hist"]), nat.ptr(stt["alive"])),
+                                             nat.ptr(stt["tile_hist"]), nat.ptr(stt["alive"] if reduce else None)),
                   "wb_cascade_launch")
         return stt
 
