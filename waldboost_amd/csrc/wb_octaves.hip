@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void octaves_block_kernel(const T *img, int64_
     constexpr int OB = Blk<T>::OB, OB_LEVELS = Blk<T>::LEVELS;
     __shared__ __attribute__((aligned(16))) T bufA[OB * OB];
     __shared__ T bufB[(OB / 2) * (OB / 2)];
-    __shared__ uint32_t red[8];
+    __shared__ uint32_t red[4][2 * (OB_LEVELS + 1)];      // per wave: (max ~key, max key) of octaves 0..OB_LEVELS
 
     const int b = blockIdx.y;
     const int by = blockIdx.x / blocks_x, bx = blockIdx.x - by * blocks_x;
@@ -159,7 +159,13 @@ __global__ __launch_bounds__(256) void octaves_block_kernel(const T *img, int64_
         }
     }
     __syncthreads();
-    block_minmax_commit(nlo, hi, red, mm);
+    // per-thread partial (max ~key, max key) of every octave this block touches; ONE workgroup reduction
+    // and one atomic per value at the very end (a reduction + two atomics per octave cost two barriers each)
+    uint32_t pmm[2 * (OB_LEVELS + 1)];
+#pragma unroll
+    for (int j = 0; j < 2 * (OB_LEVELS + 1); ++j) pmm[j] = 0u;
+    pmm[0] = nlo;
+    pmm[1] = hi;
 
     // ---- octaves 1..7: pool LDS -> LDS (+ global), ping-pong between bufA and bufB
     T *cur = bufA;
@@ -187,11 +193,35 @@ __global__ __launch_bounds__(256) void octaves_block_kernel(const T *img, int64_
             }
         }
         __syncthreads();
-        block_minmax_commit(nlo, hi, red, mm + 2 * k);
+#pragma unroll
+        for (int j = 1; j <= OB_LEVELS; ++j)          // (static indexing keeps pmm in registers)
+            if (j == k) {
+                pmm[2 * j] = nlo;
+                pmm[2 * j + 1] = hi;
+            }
         T *t = cur;
         cur = nxt;
         nxt = t;
         side = ns;
+    }
+    // ---- min/max of all octaves: wave reduction, exchange through LDS, then lane j commits value j
+    const int nval = 2 * (kmax + 1);
+#pragma unroll
+    for (int j = 0; j < 2 * (OB_LEVELS + 1); ++j) {
+        uint32_t v = pmm[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            uint32_t w = __shfl_xor(v, o);
+            v = w > v ? w : v;
+        }
+        if ((tid & 63) == 0) red[tid >> 6][j] = v;
+    }
+    __syncthreads();
+    if (tid < nval) {
+        uint32_t v = red[0][tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v = red[w][tid] > v ? red[w][tid] : v;
+        if (v) atomicMax(mm + tid, v);                 // mm is [octave][2]: index 2*k + {0: ~min key, 1: max key}
     }
 }
 
