@@ -663,31 +663,45 @@ __global__ __launch_bounds__(256) void channels_u1_kernel(ChanArgs a) {
     // ---- step 2: integer gradients -> channels -> shrink, one shrunk pixel per iteration
     for (int p = tid; p < SU * SV; p += 256) {
         const int i = p / SV, j = p - i * SV;
-        int pt[P][P];
+        // The stencils in fp32 (exact: integers below 2^11), shared [1,2,1] passes as in channels_kernel;
+        // only the channel values are converted to integers.  trunc((dx -/+ dy) / 2) has the magnitude
+        // floor(|dx -/+ dy| / 2), so  |y| // 4  is  |dx| >> 2, |dx - dy| >> 3, |dy| >> 2, |dx + dy| >> 3;
+        // with 8 bit pixels |dx|, |dy| <= 1020, so none of them exceeds 255 and the clamp never acts.
+        float pt[P][P];
 #pragma unroll
         for (int y = 0; y < P; ++y)
 #pragma unroll
-            for (int x = 0; x < P; ++x) pt[y][x] = (int)R[(S * i + y) * RW + (S * j + x)];
+            for (int x = 0; x < P; ++x) pt[y][x] = R[(S * i + y) * RW + (S * j + x)];
+        float hc[S][P], hr[P][S];
+#pragma unroll
+        for (int y = 0; y < S; ++y)
+#pragma unroll
+            for (int x = 0; x < P; ++x) hc[y][x] = scalar_only(Src<T>::hpass(pt[y][x], pt[y + 1][x], pt[y + 2][x]));
+#pragma unroll
+        for (int y = 0; y < P; ++y)
+#pragma unroll
+            for (int x = 0; x < S; ++x) hr[y][x] = scalar_only(Src<T>::hpass(pt[y][x], pt[y][x + 1], pt[y][x + 2]));
+        // numba leaves the 1-pixel border of the resized image at 0: only blocks on that border test their pixels
+        const int by0 = ry0 + S * i + 1, bx0 = rx0 + S * j + 1;                    // first pixel of the block
+        const bool on_border = by0 <= 0 || bx0 <= 0 || by0 + S - 1 >= L.nh - 1 || bx0 + S - 1 >= L.nw - 1;
         int ch[S][S][NCH];
 #pragma unroll
         for (int y = 0; y < S; ++y)
 #pragma unroll
             for (int x = 0; x < S; ++x) {
-                int dx = -(pt[y][x] + 2 * pt[y + 1][x] + pt[y + 2][x]) + pt[y][x + 2] + 2 * pt[y + 1][x + 2] + pt[y + 2][x + 2];
-                int dy = -(pt[y][x] + 2 * pt[y][x + 1] + pt[y][x + 2]) + pt[y + 2][x] + 2 * pt[y + 2][x + 1] + pt[y + 2][x + 2];
-                const int gy = ry0 + S * i + y + 1, gx = rx0 + S * j + x + 1;      // position in the resized image
-                if (gy <= 0 || gx <= 0 || gy >= L.nh - 1 || gx >= L.nw - 1) dx = dy = 0;
+                float dx = scalar_only(hc[y][x + 2] - hc[y][x]);
+                float dy = scalar_only(hr[y + 2][x] - hr[y][x]);
+                if (on_border) {
+                    const int gy = by0 + y, gx = bx0 + x;
+                    if (gy <= 0 || gx <= 0 || gy >= L.nh - 1 || gx >= L.nw - 1) dx = dy = 0.0f;
+                }
                 if constexpr (NCH == 4) {
-                    const int y4[4] = {dx, (dx - dy) / 2, dy, (dx + dy) / 2};      // C division truncates toward zero
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int v = (y4[k] < 0 ? -y4[k] : y4[k]) >> 2;
-                        ch[y][x][k] = v < 255 ? v : 255;
-                    }
+                    ch[y][x][0] = (int)(uint32_t)fabsf(dx) >> 2;
+                    ch[y][x][1] = (int)(uint32_t)fabsf(dx - dy) >> 3;
+                    ch[y][x][2] = (int)(uint32_t)fabsf(dy) >> 2;
+                    ch[y][x][3] = (int)(uint32_t)fabsf(dx + dy) >> 3;
                 } else {
-                    const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
-                    const int v = (ax > ay ? ax : ay) >> 2;
-                    ch[y][x][0] = v < 255 ? v : 255;
+                    ch[y][x][0] = (int)(uint32_t)fmaxf(fabsf(dx), fabsf(dy)) >> 2;
                 }
             }
         uint32_t o = 0;
