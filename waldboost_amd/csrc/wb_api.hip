@@ -42,7 +42,11 @@ int tree_depth(const TreeView &t, int node) {
 // Fill the complete depth-D tree rooted at canonical node `ci` (BFS numbering: children of i are
 // 2i+1, 2i+2) from reference node `node`.  A reference leaf above depth D becomes a dummy split
 // (feature offset 0, both subtrees = that leaf), which cannot change the leaf value reached.
-void fill(const TreeView &t, int node, int ci, int d, int D, int rows, int pitch, int32_t *off, float *thr,
+// BYTES: records for uint8 channels -- offsets address the interleaved byte tile [row][col][C], thresholds are
+// integers (stored in the float slots): for an integer pixel v, `v <= thr` is `v <= floor(thr)`; a NaN or negative
+// threshold is never met (-1), anything from 255 up always (255).
+template <bool BYTES>
+void fill(const TreeView &t, int node, int ci, int d, int D, int rows, int pitch, int C, int32_t *off, float *thr,
           float *pred) {
     const int NI = (1 << D) - 1;
     if (d == D) {
@@ -52,15 +56,22 @@ void fill(const TreeView &t, int node, int ci, int d, int D, int rows, int pitch
     if (t.left[node] < 0) {
         off[ci] = 0;
         thr[ci] = 0.0f;
-        fill(t, node, 2 * ci + 1, d + 1, D, rows, pitch, off, thr, pred);
-        fill(t, node, 2 * ci + 2, d + 1, D, rows, pitch, off, thr, pred);
+        fill<BYTES>(t, node, 2 * ci + 1, d + 1, D, rows, pitch, C, off, thr, pred);
+        fill<BYTES>(t, node, 2 * ci + 2, d + 1, D, rows, pitch, C, off, thr, pred);
         return;
     }
     int fr = t.feature[node * 3 + 0], fc = t.feature[node * 3 + 1], ch = t.feature[node * 3 + 2];
-    off[ci] = ((ch * rows + fr) * pitch + fc) * 4;       // byte offset inside the LDS tile
-    thr[ci] = t.threshold[node];
-    fill(t, t.left[node], 2 * ci + 1, d + 1, D, rows, pitch, off, thr, pred);
-    fill(t, t.right[node], 2 * ci + 2, d + 1, D, rows, pitch, off, thr, pred);
+    if (BYTES) {
+        off[ci] = (fr * pitch + fc) * C + ch;
+        const float th = t.threshold[node];
+        int32_t ti = !(th >= 0.0f) ? -1 : (th >= 255.0f ? 255 : (int32_t)floorf(th));
+        memcpy(&thr[ci], &ti, 4);
+    } else {
+        off[ci] = ((ch * rows + fr) * pitch + fc) * 4;   // byte offset inside the LDS tile
+        thr[ci] = t.threshold[node];
+    }
+    fill<BYTES>(t, t.left[node], 2 * ci + 1, d + 1, D, rows, pitch, C, off, thr, pred);
+    fill<BYTES>(t, t.right[node], 2 * ci + 2, d + 1, D, rows, pitch, C, off, thr, pred);
 }
 
 }  // namespace
@@ -126,6 +137,8 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         M->lds_stages = (n_stages * WB_STAGE_DWORDS(D) * 4 <= 16 * 1024) ? n_stages : 0;
         M->lds_bytes = ((C * M->lds_rows * M->lds_pitch * 4 + M->tile_rows * WB_CASC_TC * 8 + n_stages * 4 + 15) & ~15) +
                        M->lds_stages * WB_STAGE_DWORDS(D) * 4;
+        M->lds_bytes_u8 = ((((C * M->lds_rows * M->lds_pitch + 15) & ~15) + M->tile_rows * WB_CASC_TC * 8 + n_stages * 4 + 15) & ~15) +
+                          M->lds_stages * WB_STAGE_DWORDS(D) * 4;
         if (M->lds_bytes <= budget || rpw <= 1) break;
     }
     if (!generic && M->lds_bytes > 160 * 1024) {
@@ -179,19 +192,29 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
     const int NI = (1 << D) - 1, NL = 1 << D, SD = M->stage_dwords;
     // G trailing no-op records (offset 0, prediction 0, theta -inf) so a group load never leaves the table
     const int G = wb_cascade_group(D);
-    std::vector<int32_t> packed((size_t)(n_stages + G) * SD, 0);
-    for (int s = n_stages; s < n_stages + G; ++s) reinterpret_cast<float *>(packed.data() + (size_t)s * SD)[2 * NI + NL] = -INFINITY;
+    std::vector<int32_t> packed((size_t)(n_stages + G) * SD, 0), packed8((size_t)(n_stages + G) * SD, 0);
+    for (int s = n_stages; s < n_stages + G; ++s) {
+        reinterpret_cast<float *>(packed.data() + (size_t)s * SD)[2 * NI + NL] = -INFINITY;
+        reinterpret_cast<float *>(packed8.data() + (size_t)s * SD)[2 * NI + NL] = -INFINITY;
+    }
     for (int s = 0; s < n_stages; ++s) {
-        int32_t *rec = packed.data() + (size_t)s * SD;
-        int32_t *off = rec;
-        float *thr = reinterpret_cast<float *>(rec + NI);
-        float *pred = reinterpret_cast<float *>(rec + 2 * NI);
-        fill(trees[s], 0, 0, 0, D, M->lds_rows, M->lds_pitch, off, thr, pred);
-        reinterpret_cast<float *>(rec)[2 * NI + NL] = theta[s];
+        for (int bytes = 0; bytes < 2; ++bytes) {
+            int32_t *rec = (bytes ? packed8 : packed).data() + (size_t)s * SD;
+            int32_t *off = rec;
+            float *thr = reinterpret_cast<float *>(rec + NI);
+            float *pred = reinterpret_cast<float *>(rec + 2 * NI);
+            if (bytes)
+                fill<true>(trees[s], 0, 0, 0, D, M->lds_rows, M->lds_pitch, C, off, thr, pred);
+            else
+                fill<false>(trees[s], 0, 0, 0, D, M->lds_rows, M->lds_pitch, C, off, thr, pred);
+            reinterpret_cast<float *>(rec)[2 * NI + NL] = theta[s];
+        }
     }
     {
         hipError_t e = hipMalloc((void **)&M->stages_dev, packed.size() * 4);
         if (e == hipSuccess) e = hipMemcpy(M->stages_dev, packed.data(), packed.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void **)&M->stages_u8_dev, packed8.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(M->stages_u8_dev, packed8.data(), packed8.size() * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             wb_set_error("wb_model_create: uploading %zu stage bytes failed: %s", packed.size() * 4, hipGetErrorString(e));
             wb_model_destroy(M);
@@ -210,6 +233,7 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
 extern "C" int wb_model_destroy(WbModel *model) {
     if (!model) return WB_OK;
     if (model->stages_dev) (void)hipFree(model->stages_dev);
+    if (model->stages_u8_dev) (void)hipFree(model->stages_u8_dev);
     void *g[] = {model->g_node_off, model->g_feat, model->g_thr, model->g_left, model->g_right, model->g_pred, model->g_theta};
     for (void *p : g)
         if (p) (void)hipFree(p);

@@ -109,26 +109,32 @@ template <int D> struct Stage {
     }
     // walk the complete depth-D tree for the window whose origin is at BYTE offset `base` of the
     // LDS tile (offsets in the records are bytes too: one v_add per gather)
-    __device__ inline float eval(const float *tile, int base) const {
+    // BYTES: the tile holds uint8 pixels ([row][col][C] bytes), the record's offsets address it and its
+    // thresholds are integers (wb_api.hip: fill<true>): an 8-bit gather and an integer compare per node.
+    template <bool BYTES> static __device__ inline bool goes_right(const char *t8, int at, float th) {
+        if constexpr (BYTES) {
+            const int v = *reinterpret_cast<const uint8_t *>(t8 + at);
+            return !(v <= __float_as_int(th));
+        } else {
+            const float v = *reinterpret_cast<const float *>(t8 + at);
+            return !(v <= th);                         // NaN goes right, like the reference's `<=`
+        }
+    }
+    template <bool BYTES = false> __device__ inline float eval(const float *tile, int base) const {
         const char *t8 = reinterpret_cast<const char *>(tile);
         bool right[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) right[d] = false;
-        {
-            float v = *reinterpret_cast<const float *>(t8 + (base + off[0]));
-            right[0] = !(v <= thr[0]);                 // NaN goes right, like the reference's `<=`
-        }
+        right[0] = goes_right<BYTES>(t8, base + off[0], thr[0]);
         if constexpr (D > 1) {
             int o = Sel<2, int>::get(off + 1, right);
             float th = Sel<2, float>::get(thr + 1, right);
-            float v = *reinterpret_cast<const float *>(t8 + (base + o));
-            right[1] = !(v <= th);
+            right[1] = goes_right<BYTES>(t8, base + o, th);
         }
         if constexpr (D > 2) {
             int o = Sel<4, int>::get(off + 3, right);
             float th = Sel<4, float>::get(thr + 3, right);
-            float v = *reinterpret_cast<const float *>(t8 + (base + o));
-            right[2] = !(v <= th);
+            right[2] = goes_right<BYTES>(t8, base + o, th);
         }
         return Sel<NL, float>::get(pred, right);
     }
@@ -165,16 +171,18 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     const int T = a.T;
 
     float *tile = reinterpret_cast<float *>(smem);
-    const int tile_floats = a.C * rows * pitch;
-    uint2 *queue = reinterpret_cast<uint2 *>(smem + (size_t)tile_floats * 4) + wave * (RPW * 64);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem + (size_t)tile_floats * 4 + (size_t)TR * 64 * 8);
+    // float32 channels: planar float tile [C][rows][pitch]; uint8 channels: the pixels as they are, [rows][pitch][C] bytes
+    const size_t tile_bytes = U8 ? (((size_t)a.C * rows * pitch + 15) & ~(size_t)15) : (size_t)a.C * rows * pitch * 4;
+    const int px_stride = U8 ? a.C : 4;                      // bytes between horizontally adjacent windows' origins
+    uint2 *queue = reinterpret_cast<uint2 *>(smem + tile_bytes) + wave * (RPW * 64);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem + tile_bytes + (size_t)TR * 64 * 8);
 
     const int nr = L.u - a.m > 0 ? L.u - a.m : 0;          // window grid
     const int nc = L.v - a.n > 0 ? L.v - a.n : 0;
     const int r0 = tile_d.ty * TR, c0 = tile_d.tx * WB_CASC_TC;
 
     // LDS mirror of the stage table (when it is small enough): the tail reads one record per lane
-    int4 *stab = reinterpret_cast<int4 *>(smem + (((size_t)tile_floats * 4 + (size_t)TR * 64 * 8 + (size_t)T * 4 + 15) & ~(size_t)15));
+    int4 *stab = reinterpret_cast<int4 *>(smem + ((tile_bytes + (size_t)TR * 64 * 8 + (size_t)T * 4 + 15) & ~(size_t)15));
     WB_STAMP(0);
     for (int t = tid; t < T; t += NT) hist[t] = 0;
     for (int i = tid; i < a.lds_stages * (SD / 4); i += NT) stab[i] = reinterpret_cast<const int4 *>(stages)[i];
@@ -184,18 +192,16 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     const uint8_t *chn8 = reinterpret_cast<const uint8_t *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
     if (a.dbg & 1) {
     } else if (U8 && a.C == 4 && (pitch & 3) == 0) {
-        // uint8 channels, one dword per pixel, 16 bytes = FOUR pixels per lane and load: a quarter of the
-        // float path's load instructions for a quarter of its bytes.  The 16 values are widened to their
-        // exact float32 values (uint8 <= float32 compares in float32 under NumPy promotion, so the stage
-        // loop is unchanged) and leave as one 16-byte LDS store per channel plane.  A group may read up to
-        // 12 bytes past the end of a level row (the buffers carry 16 spare bytes); those pixels land in
-        // columns no window of the level reads.
+        // uint8 channels, one dword per pixel, kept as they are: the tile is [rows][pitch] dwords, a quarter of
+        // the float tile (twice the workgroups per CU), loaded 16 bytes = FOUR pixels per lane, stored with one
+        // 16-byte LDS write.  A group may read up to 12 bytes past the end of a level row (the buffers carry
+        // 16 spare bytes); those pixels land in columns no window of the level reads.
         constexpr int U = 2;
         const int ngrp = (WB_CASC_TC + a.n - 1 + 3) >> 2;            // 4-pixel groups per tile row (<= pitch / 4)
         const int total = rows * ngrp;
         const uint32_t m_ngrp = 0xFFFFFFFFu / (uint32_t)ngrp + 1u;
-        const int plane = rows * pitch;
         struct __attribute__((aligned(4))) Px4 { uint32_t x, y, z, w; };      // four pixels, dword-aligned only
+        uint32_t *tile32 = reinterpret_cast<uint32_t *>(smem);
         for (int e0 = tid; e0 < total; e0 += NT * U) {
             Px4 v[U];
             int dst[U];
@@ -211,51 +217,20 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
                 dst[k] = (int)(row * (uint32_t)pitch + 4u * grp);
             }
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const uint32_t px[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-#pragma unroll
-                for (int ch = 0; ch < 4; ++ch) {
-                    float4 f;
-                    f.x = (float)((px[0] >> (8 * ch)) & 255u);
-                    f.y = (float)((px[1] >> (8 * ch)) & 255u);
-                    f.z = (float)((px[2] >> (8 * ch)) & 255u);
-                    f.w = (float)((px[3] >> (8 * ch)) & 255u);
-                    *reinterpret_cast<float4 *>(tile + dst[k] + ch * plane) = f;
-                }
-            }
+            for (int k = 0; k < U; ++k) *reinterpret_cast<uint4 *>(tile32 + dst[k]) = make_uint4(v[k].x, v[k].y, v[k].z, v[k].w);
         }
-    } else if (U8 && a.C == 4) {
-        // uint8 channels, one dword per pixel: same batched scheme as the float4 path below; the
-        // four bytes are widened to their exact float32 values on the way into the LDS planes
-        // (uint8 <= float32 compares in float32 under NumPy promotion), so the stage loop is unchanged
-        constexpr int U = 8;
-        const int ncol = WB_CASC_TC + a.n - 1;
-        const int total = rows * ncol;
-        const uint32_t m_ncol = 0xFFFFFFFFu / (uint32_t)ncol + 1u;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(chn8);
-        const int plane = rows * pitch;
-        for (int e0 = tid; e0 < total; e0 += NT * U) {
-            uint32_t v[U];
-            int dst[U];
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                uint32_t e = (uint32_t)(e0 + k * NT);
-                const bool in = e < (uint32_t)total;
-                e = in ? e : (uint32_t)total - 1u;
-                uint32_t row = __umulhi(e, m_ncol), col = e - row * (uint32_t)ncol;
-                int gr = r0 + (int)row, gc = c0 + (int)col;
-                gr = gr < L.u ? gr : L.u - 1;
-                gc = gc < L.v ? gc : L.v - 1;
-                v[k] = src[(int64_t)gr * L.v + gc];
-                dst[k] = in ? (int)(row * (uint32_t)pitch + col) : plane - 1;
-            }
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                tile[dst[k]] = (float)(v[k] & 255u);
-                tile[dst[k] + plane] = (float)((v[k] >> 8) & 255u);
-                tile[dst[k] + 2 * plane] = (float)((v[k] >> 16) & 255u);
-                tile[dst[k] + 3 * plane] = (float)(v[k] >> 24);
-            }
+    } else if (U8) {
+        // uint8 channels of any count: the byte tile [rows][pitch][C], element by element
+        uint8_t *tile8 = reinterpret_cast<uint8_t *>(smem);
+        const int total = a.C * rows * pitch;
+        for (int idx = tid; idx < total; idx += NT) {
+            const int ch = idx % a.C;
+            const int rc = idx / a.C;
+            const int col = rc % pitch, row = rc / pitch;
+            const int gr = r0 + row, gc = c0 + col;
+            uint8_t v = 0;
+            if (gr < L.u && gc < L.v) v = chn8[((int64_t)gr * L.v + gc) * a.C + ch];
+            tile8[idx] = v;
         }
     } else if (a.C == 4) {
         // Channels live in HBM as one float4 per pixel ([u][v][4]): a tile row is ONE contiguous
@@ -304,7 +279,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
             float v = 0.f;
             if (gr < L.u && gc < L.v) {
                 const int64_t at = ((int64_t)gr * L.v + gc) * a.C + ch;
-                v = U8 ? (float)chn8[at] : chn[at];
+                v = chn[at];
             }
             tile[(ch * rows + row) * pitch + col] = v;
         }
@@ -322,7 +297,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     for (int j = 0; j < RPW; ++j) {
         hs[j] = 0.f;
         lm[j] = __ballot((c0 + lane < nc) && (r0 + wr + j < nr));
-        base[j] = ((wr + j) * pitch + lane) * 4;
+        base[j] = ((wr + j) * pitch + lane) * px_stride;
     }
     const int tA = T < S0 ? T : S0;
     static_assert(S0 <= 64, "one lane per phase-A stage");
@@ -336,7 +311,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int j = 0; j < RPW; ++j) p[g][j] = st[g].eval(tile, base[j]);
+            for (int j = 0; j < RPW; ++j) p[g][j] = st[g].template eval<U8>(tile, base[j]);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (t + g >= tA) break;
@@ -366,7 +341,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
     for (int j = 0; j < RPW; ++j) my_cnt += __popcll(lm[j]);
     uint32_t total = (uint32_t)my_cnt, before = 0;
     bool pooled = false;
-    uint2 *wgq = reinterpret_cast<uint2 *>(smem + (size_t)tile_floats * 4);
+    uint2 *wgq = reinterpret_cast<uint2 *>(smem + tile_bytes);
     if (T > S0) {
         if (lane == 0) wcnt[wave] = (uint32_t)my_cnt;
         __syncthreads();
@@ -422,7 +397,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
                 uint2 e = mine ? queue[i] : make_uint2(0u, 0u);
                 int pos = (int)e.x;
                 float h = __uint_as_float(e.y);
-                int wbase = ((pos >> 6) * pitch + (pos & 63)) * 4;
+                int wbase = ((pos >> 6) * pitch + (pos & 63)) * px_stride;
                 for (int t = t_begin; t < t_end; t += G) {
                     if (am == 0ull) break;
                     Stage<D> st[G];
@@ -431,7 +406,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
                     for (int g = 0; g < G; ++g) st[g].load(sp + g * SD);
                     float p[G];
 #pragma unroll
-                    for (int g = 0; g < G; ++g) p[g] = st[g].eval(tile, wbase);
+                    for (int g = 0; g < G; ++g) p[g] = st[g].template eval<U8>(tile, wbase);
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         if (t + g >= t_end) break;
@@ -487,8 +462,8 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         for (int i = 0; i < n_q; ++i) {
             const uint2 e = queue[i];                            // same entry in every lane
             const int pos = (int)e.x;
-            const int wbase = ((pos >> 6) * pitch + (pos & 63)) * 4;
-            const float p = st.eval(tile, wbase);
+            const int wbase = ((pos >> 6) * pitch + (pos & 63)) * px_stride;
+            const float p = st.template eval<U8>(tile, wbase);
             // Replay in stage order: lane k accumulates p_0 .. p_k one after the other -- the same
             // additions in the same order as the reference's running `hs +=` -- so it ends up
             // with the score the rejection test of stage rs+k sees.
@@ -842,7 +817,7 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
     a.levels = levels;
     a.tiles = tiles;
     a.n_levels = n_levels;
-    a.stages = model->stages_dev;
+    a.stages = a.chn_u8 ? model->stages_u8_dev : model->stages_dev;
     a.T = model->n_stages;
     a.m = model->m;
     a.n = model->n;
@@ -886,10 +861,11 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
         WB_HIP_CHECK(hipGetLastError());
         return WB_OK;
     }
+    const size_t lds = (size_t)(a.chn_u8 ? model->lds_bytes_u8 : model->lds_bytes);
     switch (model->depth) {
-        case 1: return launch_depth<1>(st, grid, a, model->rpw, model->waves, (size_t)model->lds_bytes);
-        case 2: return launch_depth<2>(st, grid, a, model->rpw, model->waves, (size_t)model->lds_bytes);
-        case 3: return launch_depth<3>(st, grid, a, model->rpw, model->waves, (size_t)model->lds_bytes);
+        case 1: return launch_depth<1>(st, grid, a, model->rpw, model->waves, lds);
+        case 2: return launch_depth<2>(st, grid, a, model->rpw, model->waves, lds);
+        case 3: return launch_depth<3>(st, grid, a, model->rpw, model->waves, lds);
     }
     wb_set_error("wb_cascade_launch: model depth %d has no kernel", model->depth);
     return WB_ERR_UNSUPPORTED;

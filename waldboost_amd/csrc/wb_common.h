@@ -68,7 +68,9 @@ struct WbModel {
     int lds_bytes;
     int lds_stages;   // stage records mirrored in LDS (n_stages if the table is <= 16 KiB, else 0)
     int stage_dwords;
-    int32_t *stages_dev;        // (n_stages + G) stage records with LDS byte offsets
+    int32_t *stages_dev;        // (n_stages + G) stage records with LDS byte offsets (planar float32 tile)
+    int32_t *stages_u8_dev;     // the same for uint8 channels: offsets into the interleaved byte tile, integer thresholds
+    int lds_bytes_u8;           // dynamic LDS of the kernel on uint8 channels
     // trees deeper than WB_CASC_MAX_DEPTH: generic node-walk kernel on the reference's own flat arrays
     int generic;                // 1 = use cascade_generic_kernel
     int32_t *g_node_off;        // [n_stages + 1]
