@@ -138,6 +138,42 @@ def test_u1_detect_other_window_shapes(fn, window):
     assert np.array_equal(bits(res["scores"]), bits(ref["scores"]))
 
 
+@pytest.mark.parametrize("fn", sorted(FUNCS))
+def test_u1_cascade_threshold_corner_values(fn):
+    """The uint8 cascade compares pixels with integerised thresholds: negative, -0.0, fractional, exactly integral,
+    254.5 / 255 / above 255, +-inf and NaN thresholds must route windows like NumPy's `uint8 <= float32`."""
+    rng = np.random.default_rng(12)
+    C = 4 if fn == "grad_hist_4_u1" else 1
+    shape = (12, 12, C)
+    special = np.array([-5.5, -0.0, 0.0, 0.5, 1.0, 2.999, 3.0, 17.25, 254.5, 255.0, 255.5, 300.0, np.inf, -np.inf, np.nan], np.float32)
+    M = wb.Model(shape, dict(shrink=2, n_per_oct=8, smooth=1, channels=FUNCS[fn]))
+    acc = 0.0
+    for t in range(36):
+        f, th, l, r, p = random_tree_arrays(rng, shape, 2 if t % 4 else 3, 1.0, 20.0)
+        pick = rng.random(th.size) < 0.5
+        th = np.where(pick, rng.choice(special, th.size), th).astype(np.float32)
+        acc += -0.2
+        M.append(wb.DTree(f, th, l, r, p), float("-inf") if t % 6 == 5 else float(np.float32(acc)))
+    img = synth_image(180, 260, 5)
+    img[40:90, 60:140] = 255                      # saturated block: channel values 0 and large
+    img[100:140, 20:100] = 0
+    with np.errstate(invalid="ignore"):
+        ref = oracle_detect(M, img)
+    res = M.detect_raw(img)
+    assert ref["scores"].size > 0
+    assert np.array_equal(res["alive"], ref["alive"]) and np.array_equal(res["level"], ref["level"])
+    assert np.array_equal(res["r"], ref["r"]) and np.array_equal(res["c"], ref["c"])
+    assert np.array_equal(bits(res["scores"]), bits(ref["scores"]))
+    # the same trees on explicit window lists and on samples (tree_eval / tree_apply kernels: float compares)
+    chns, _ = next(iter(wb.channels.channel_pyramid(img, M.channel_opts)))
+    rs, cs = np.indices((chns.shape[0] - 12, chns.shape[1] - 12))
+    rs, cs = rs.flatten()[::11], cs.flatten()[::11]
+    for w in M.classifier[:6]:
+        tree = orc.make_tree(w.feature, w.threshold, w.left, w.right, w.prediction)
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(bits(w.predict_on_image(chns, rs, cs)), bits(orc.tree_predict_on_image(tree, chns, rs, cs)))
+
+
 def test_u1_batch_and_tree_eval():
     fn = "grad_hist_4_u1"
     M = u1_model(fn, 9, 24, 2, 1.0, 20.0)

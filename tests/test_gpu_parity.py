@@ -228,6 +228,38 @@ def test_detect_mixed_depths_float_image_and_odd_window():
     assert_same_detections(res, ref)
 
 
+def test_special_threshold_and_prediction_values():
+    """NaN / +-inf / -0.0 thresholds (a NaN comparison is False: the window goes right) and stages whose
+    rejection threshold is -inf, +inf or NaN, on float32 channels."""
+    rng = np.random.default_rng(31)
+    shape = (12, 12, 4)
+    special = np.array([np.nan, np.inf, -np.inf, -0.0, 0.0, 1e-30, 3.0e38], np.float32)
+    M = wb.Model(shape, dict(wb.default_channel_opts))
+    acc = 0.0
+    for t in range(30):
+        f, th, l, r, p = random_tree_arrays(rng, shape, 2, 2.0, 60.0)
+        th = np.where(rng.random(th.size) < 0.4, rng.choice(special, th.size), th).astype(np.float32)
+        acc += -0.25
+        theta = [float(np.float32(acc)), float("-inf"), float(np.float32(acc))][t % 3]
+        M.append(wb.DTree(f, th, l, r, p), theta)
+    img = synth_image(190, 250, 77)
+    with np.errstate(invalid="ignore"):
+        ref = oracle_detect(M, img)
+    res = M.detect_raw(img)
+    assert ref["scores"].size > 0
+    assert_same_detections(res, ref)
+    # a NaN stage threshold rejects everything (x >= NaN is False), +inf likewise
+    for bad in (float("nan"), float("inf")):
+        M2 = wb.Model(shape, dict(wb.default_channel_opts))
+        for i, (w, th) in enumerate(M):
+            M2.append(w, bad if i == 4 else th)
+        with np.errstate(invalid="ignore"):
+            ref2 = oracle_detect(M2, img)
+        res2 = M2.detect_raw(img)
+        assert ref2["scores"].size == 0 and res2["scores"].size == 0
+        assert np.array_equal(res2["alive"], ref2["alive"])
+
+
 def test_predict_on_image_and_tree_eval_vs_oracle():
     rng = np.random.default_rng(5)
     X = rng.uniform(0, 60, (70, 150, 4)).astype(np.float32)
