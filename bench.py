@@ -66,6 +66,30 @@ def cpu_baseline(model_path, images_per_core=6, max_cores=16):
 
 
 # ----------------------------------------------------------------------------- helpers
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+N_SIMD, CLOCK_GHZ = 256 * 4, 2.4          # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz max clock
+
+
+def issue_bound(roof, batch, channels):
+    """The bound that actually binds these kernels: vector-instruction issue.  From the committed SQ counters
+    (rocprofv3 --pmc passes, profiles/r02/sq_counters.json: instructions per launch per image), a wave64 VALU
+    instruction occupies its SIMD's issue port for at least 2 cycles (4 for conversions, fp64, transcendental),
+    so `floor_us` = VALU instructions x 2 cycles / (1024 SIMDs x 2.4 GHz) is the time the dominant kernel's
+    instruction stream needs if nothing ever stalls; `frac` = floor / measured duration."""
+    path = os.path.join(PROFILE_DIR, "sq_counters.json")
+    if roof is None or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        cj = json.load(f)
+    k = cj.get(channels, {}).get(roof["kernel"])
+    if not k:
+        return None
+    valu, salu = k["SQ_INSTS_VALU_per_image"] * batch, k["SQ_INSTS_SALU_per_image"] * batch
+    floor_us = valu * 2.0 / (N_SIMD * CLOCK_GHZ * 1e3)
+    return {"kernel": roof["kernel"], "bound": "valu_issue", "valu_insts_per_launch": valu, "salu_insts_per_launch": salu,
+            "floor_us": floor_us, "measured_us": roof["avg_launch_ms"] * 1e3, "frac": floor_us / (roof["avg_launch_ms"] * 1e3),
+            "counters": "profiles/r02/sq_counters.json", "note": "wave64 VALU = 2 issue cycles minimum; 1024 SIMDs at 2.4 GHz"}
+
 def event_time_ms(fn, iters, torch):
     """Average duration of fn() over `iters` back-to-back launches, HIP events on the launch stream."""
     fn()
@@ -89,7 +113,11 @@ def main():
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the steps are spread over (<= pool): consecutive steps work on different "
                          "images, so their kernels may overlap on the GPU like frames of a video pipeline")
+    ap.add_argument("--repeats", type=int, default=10,
+                    help="the timed region of --steps steps is run this many times; `value` is the median region, "
+                         "`value_spread` carries min/max")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-through-api", action="store_true", help="skip the host ndarray -> Boxes measurement (Model.detect)")
     ap.add_argument("--channels", choices=sorted(MODELS), default="grad_hist",
                     help="channel function of the workload; grad_hist is the BASELINE config, grad_hist_4_u1 the "
                          "reference's integer channels (same geometry, uint8 channels, its own calibrated cascade)")
@@ -143,30 +171,14 @@ def main():
     n_loc = plan.n_loc(dm.m, dm.n)
     torch.cuda.synchronize()
 
-    # ---- parity gate before timing: rank 0, engine 0, image 0 against the oracle
-    parity = None
-    if rank == 0 and args.only == "all" and not args.stages:
-        from util import oracle_detect
-        e = engines[0]
-        stt = e.run(dm)
-        n_det = e.ensure_capacity(dm)
-        d = e.sorted_detections().cpu().numpy().view(nat.DET_DTYPE).reshape(-1)
-        d0 = d[d["image"] == 0]
-        alive0 = stt["alive"][0, :, :len(M)].cpu().numpy().astype(np.int64)
-        ref = oracle_detect(M, synth_image(H, W, (rank * P) * B))
-        ok = (np.array_equal(d0["level"], ref["level"]) and np.array_equal(d0["r"], ref["r"]) and
-              np.array_equal(d0["c"], ref["c"]) and np.array_equal(d0["score"].view(np.uint32), ref["scores"].view(np.uint32)) and
-              np.array_equal(alive0, ref["alive"]))
-        if not ok:
-            raise SystemExit("bench: GPU detections differ from the oracle -- refusing to time a wrong kernel")
-        parity = {"image": "seed 0", "detections": int(ref["scores"].size), "eval_cost": ref["n_weak"] / ref["n_loc"], "bit_exact": True}
-
     # every engine holds valid octaves / channels / detections before any partial loop is timed
     for e in engines:
         e.run(dm)
     torch.cuda.synchronize()
 
-    # ---- step functions
+    # ---- step functions (fused: the channel kernel writes the channels as threshold ranks of the cascade, one byte
+    #      each, and the cascade scans those -- what PyramidEngine.run / Model.detect do when the model allows it)
+    fused = engines[0].ranks_for(dm)
     if args.only == "all":
         if args.no_graph:
             steps = [(lambda e=e: e.run(dm)) for e in engines]
@@ -174,11 +186,38 @@ def main():
             graphs = [e.capture(dm) for e in engines]
             steps = [g.replay for g in graphs]
     elif args.only == "channels":
-        steps = [e.launch_channels for e in engines]
+        steps = [(lambda e=e: e.launch_channels(dm if fused else None, floats=not fused)) for e in engines]
     elif args.only == "octaves":
         steps = [e.launch_octaves for e in engines]
     else:
-        steps = [(lambda e=e: e.run_cascade(dm)) for e in engines]
+        steps = [(lambda e=e: e.run_cascade(dm, ranks=fused)) for e in engines]
+
+    # ---- parity gate before timing, on the path that is timed: engine 0's step (a hipGraph replay unless
+    #      --no-graph) runs once more and what IT wrote -- detections and alive[level, stage] of the first and the
+    #      last image of the batch -- is compared with the oracle, bit for bit
+    parity = None
+    if rank == 0 and args.only == "all" and not args.stages:
+        from util import oracle_detect
+        e = engines[0]
+        e.detb.counts.fill_(0x7fffffff)                      # stale values the step must overwrite
+        e._casc_state(dm)["alive"].fill_(-1)
+        steps[0]()
+        torch.cuda.synchronize()
+        if e.detb.max_count() > e.detb.cap:
+            raise SystemExit("bench: detection buffer overflow in the parity gate")
+        d = e.sorted_detections().cpu().numpy().view(nat.DET_DTYPE).reshape(-1)
+        alive = e._casc_state(dm)["alive"][:, :, :len(M)].cpu().numpy().astype(np.int64)
+        checked = []
+        for b in sorted({0, B - 1}):
+            db = d[d["image"] == b]
+            ref = oracle_detect(M, synth_image(H, W, (rank * P) * B + b))
+            ok = (np.array_equal(db["level"], ref["level"]) and np.array_equal(db["r"], ref["r"]) and
+                  np.array_equal(db["c"], ref["c"]) and np.array_equal(db["score"].view(np.uint32), ref["scores"].view(np.uint32)) and
+                  np.array_equal(alive[b], ref["alive"]))
+            if not ok:
+                raise SystemExit(f"bench: image {b} of the replayed step differs from the oracle -- refusing to time a wrong kernel")
+            checked.append({"image": f"seed {b}", "detections": int(ref["scores"].size), "eval_cost": ref["n_weak"] / ref["n_loc"]})
+        parity = {"path": "eager launches" if args.no_graph else "hipGraph replay", "images": checked, "bit_exact": True}
 
     gath = comm = None
     if world > 1:
@@ -215,21 +254,24 @@ def main():
             main.wait_stream(comm)
 
     run_steps(0, args.warmup)
-    torch.cuda.synchronize()
+    dts = []
+    for rep in range(max(1, args.repeats)):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(args.warmup + rep * args.steps, args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dts.append(time.perf_counter() - t0)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        tt = torch.tensor(dts, dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)            # every region: the slowest rank's time
+        dts = [float(x) for x in tt.tolist()]
+    dt = float(np.median(dts))
 
     # ---- per-kernel durations (HIP events, launch stream) and the roofline of the dominant one
     roof = None
@@ -238,19 +280,21 @@ def main():
         e = engines[0]
         it = max(20, min(args.steps, 100))
         kern["octaves_ms"] = event_time_ms(e.launch_octaves, it, torch)
-        kern["channels_ms"] = event_time_ms(e.launch_channels, it, torch)
-        kern["cascade_ms"] = event_time_ms(lambda: e.run_cascade(dm), it, torch)   # counter reset + tile kernel + statistics reduction
+        kern["channels_ms"] = event_time_ms(lambda: e.launch_channels(dm if fused else None, floats=not fused), it, torch)
+        kern["cascade_ms"] = event_time_ms(lambda: e.run_cascade(dm, ranks=fused), it, torch)   # counter reset + tile kernel + statistics reduction
         # the dominant kernel alone, as rocprofv3 sees it: cascade_tile_kernel without its follow-up reduction
         # (the counters are not reset in this loop; records past the capacity are dropped, the work is the same)
-        kern["cascade_tile_ms"] = event_time_ms(lambda: e.launch_cascade(dm, reduce=False), it, torch)
-        e.run_cascade(dm)
+        kern["cascade_tile_ms"] = event_time_ms(lambda: e.launch_cascade(dm, reduce=False, ranks=fused), it, torch)
+        e.run_cascade(dm, ranks=fused)
         ab = plan.algorithmic_bytes(1)
         name = "channels_kernel" if kern["channels_ms"] >= kern["cascade_tile_ms"] else "cascade_kernel"
         ms = kern["channels_ms"] if name == "channels_kernel" else kern["cascade_tile_ms"]
         abytes = ab[name] * B
         # HBM bytes per launch from the committed rocprofv3 PMC passes (batch-1 launches only)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_pmc.json")
+        tpath = os.path.join(PROFILE_DIR, "traffic_pmc.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r01", "traffic_pmc.json")
         if os.path.exists(tpath) and B == 1 and args.channels == "grad_hist":
             with open(tpath) as f:
                 tj = json.load(f)
@@ -259,6 +303,22 @@ def main():
         roof = {"bound": "hbm", "kernel": "channels_kernel" if name == "channels_kernel" else "cascade_tile_kernel", "achieved": abytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": ms}
+
+    # ---- the same workload through the reference's Python surface: host ndarray in, Boxes out (Model.detect,
+    #      reference model.py:149-179) -- PCIe copies, kernels, ordering, boxes, synchronisation; never `value`
+    through_api = None
+    if rank == 0 and args.only == "all" and not args.no_through_api and not args.stages:
+        imgs = [synth_image(H, W, 7000 + i) for i in range(8)]
+        for im in imgs[:3]:
+            M.detect(im)
+        torch.cuda.synchronize()
+        n_api = 40
+        t0 = time.perf_counter()
+        for i in range(n_api):
+            M.detect(imgs[i % len(imgs)])
+        t_api = (time.perf_counter() - t0) / n_api
+        through_api = {"call": "Model.detect(host uint8 ndarray) -> Boxes on the host", "ms_per_image": t_api * 1e3,
+                       "windows_per_s": n_loc / t_api, "images": n_api}
 
     if rank == 0:
         windows = world * args.steps * B * n_loc
@@ -275,13 +335,16 @@ def main():
                                    f"window (12,12,4), 128-stage depth-2 cascade, {B} image(s)/step/GPU",
                        "batch_per_gpu": B, "levels": plan.n_levels, "windows_per_image": n_loc,
                        "launch": "eager" if args.no_graph else "hipGraph replay", "only": args.only,
+                       "channels_in_hbm": "uint8 threshold ranks of the cascade (WB_DTYPE_RANK8)" if fused else spec.dtype.name,
                        "streams": n_streams, "pool": P,
                        "collective": "all_gather of detection prefix per step (side stream)" if world > 1 else "none"},
             "mpixels_per_s": world * args.steps * B * H * W / dt / 1e6,
             "images_per_s": world * args.steps * B / dt,
             "pipeline_roofline_frac": (windows / dt) * (ab["total"] / n_loc) / (HBM_PEAK_GBS * 1e9 * world),
-            "kernels": kern, "parity": parity,
-            "roofline": roof, "cpu_baseline": cpu,
+            "value_spread": {"repeats": len(dts), "min": windows / max(dts), "max": windows / min(dts),
+                             "ms_per_step_min": min(dts) / args.steps * 1e3, "ms_per_step_max": max(dts) / args.steps * 1e3},
+            "kernels": kern, "parity": parity, "through_api": through_api,
+            "roofline": roof, "issue_bound": issue_bound(roof, B, args.channels), "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:

@@ -28,6 +28,8 @@
  *        -> wb_tree_eval_launch
  *   reference waldboost/model.py:136-147 (Model.get_boxes)
  *        -> wb_boxes_launch
+ *   reference waldboost/model.py:173-179 (Model.detect: per-level results concatenated for the caller)
+ *        -> wb_det_pack_launch
  *   reference waldboost/samples.py:14-43 (gather_samples), waldboost/model.py:181-214 (Model.predict),
  *        waldboost/training.py:73-83 (DTree.apply/predict): the training-time callers of the hot path
  *        -> wb_gather_samples_launch, wb_samples_predict_launch, wb_tree_apply_launch
@@ -41,7 +43,7 @@
 extern "C" {
 #endif
 
-#define WB_ABI_VERSION 2
+#define WB_ABI_VERSION 3
 
 #define WB_OK 0
 #define WB_ERR_INVALID (-1)     /* bad argument / malformed model */
@@ -50,6 +52,14 @@ extern "C" {
 
 #define WB_DTYPE_U8 0
 #define WB_DTYPE_F32 1
+/* Channel buffers only: one byte per element holding the RANK of the float32 channel value among the distinct
+ * thresholds a given model tests on that channel (the number of them below the value; 255 for NaN).  For that
+ * model `v <= threshold` (training.py:92) is `rank(v) <= index(threshold)` for every float v, so the cascade
+ * decides exactly as on the float32 channels while reading a quarter of the bytes.  Written by
+ * wb_channels_launch(rank_model, rank), read by wb_cascade_launch(chn_dtype = WB_DTYPE_RANK8) with the SAME
+ * model.  Available when the model has 4 channels and at most 255 distinct thresholds per channel
+ * (WbModelInfo.rank_ok). */
+#define WB_DTYPE_RANK8 2
 
 /* Channel functions (channel_opts["channels"] of the reference) the channel kernel implements:
  *   WB_CHN_GRAD_HIST       waldboost.channels.grad_hist (n_bins=4)    4 x float32  channels.py:40-52
@@ -129,6 +139,7 @@ typedef struct WbModelInfo {
     int32_t tile_rows;  /* cascade tile: tile_rows x 64 windows per workgroup      */
     int32_t tile_cols;
     int32_t lds_bytes;  /* dynamic LDS per workgroup of the cascade kernel         */
+    int32_t rank_ok;    /* 1 = the model has rank tables (WB_DTYPE_RANK8 channels)  */
 } WbModelInfo;
 
 int wb_abi_version(void);
@@ -162,12 +173,18 @@ int wb_octaves_launch(void *stream, const void *img, int dtype, int batch, int H
  *   cs_sn    HOST double[8]: cos(theta_k), k=0..3 then sin(theta_k) (channels.py:43-46); used by
  *            WB_CHN_GRAD_HIST only
  *   chn      dev  [u][v][C] per level in the channel function's dtype, image b at
- *                 chn + b*chn_stride, level l at + levels[l].chn_off (elements) */
+ *                 chn + b*chn_stride, level l at + levels[l].chn_off (elements); NULL (with `rank`) = do not
+ *                 write the float32 channels at all
+ *   rank_model, rank   optional (WB_CHN_GRAD_HIST only): also write the channels as WB_DTYPE_RANK8 bytes for that
+ *                 model, same [u][v][4] layout and element offsets, image b at rank + b*rank_stride; the buffer
+ *                 must extend 16 bytes past its last element (the cascade's 16-byte group loads).  Model.detect
+ *                 (model.py:149-179) needs nothing else: the float32 pyramid then never touches HBM */
 int wb_channels_launch(void *stream, const void *img, int64_t img_stride, const void *oct,
                        int64_t oct_stride, int dtype, int batch, const WbLevel *levels, int n_levels,
                        const WbTile *tiles, int n_tiles, const uint32_t *minmax, int n_oct,
                        const WbTap *taps, int channel_func, int shrink, int smooth, const double *cs_sn,
-                       void *chn, int64_t chn_stride);
+                       void *chn, int64_t chn_stride, const WbModel *rank_model, uint8_t *rank,
+                       int64_t rank_stride);
 
 /* Build the device-side cascade from the reference's tree arrays (all HOST pointers).
  *   node_off  int32[n_stages+1]  first node of each stage's tree in the flat arrays
@@ -187,7 +204,8 @@ int wb_model_info(const WbModel *model, WbModelInfo *info);
 /* Dense sliding-window cascade over all levels of all images.
  *   chn           [u][v][C] per level as written by wb_channels_launch (or caller-provided), of
  *                 chn_dtype WB_DTYPE_F32 or WB_DTYPE_U8 (uint8 values compare against the float32
- *                 thresholds as their exact float32 values, like NumPy's uint8 <= float32); a uint8
+ *                 thresholds as their exact float32 values, like NumPy's uint8 <= float32), or
+ *                 WB_DTYPE_RANK8 (ranks of float32 channels for THIS model); a byte
  *                 buffer must extend 16 bytes past its last element (16-byte group loads)
  *   tiles         dev WbTile[n_tiles]: tiles of tile_rows x tile_cols WINDOWS over the
  *                 (u-m) x (v-n) window grid of each level
@@ -208,6 +226,15 @@ int wb_cascade_launch(void *stream, const WbModel *model, const void *chn, int c
                       const WbTile *tiles, const int32_t *tile_csr, int n_tiles, WbDet *det,
                       uint32_t *det_count, uint32_t shard_capacity, uint32_t *tile_hist,
                       uint32_t *alive);
+
+/* The valid records of all shards of a detection buffer (as wb_cascade_launch fills it), packed back to back:
+ *   packed  dev int32, 16-byte aligned: a 4-word header {valid records in all shards, fullest shard's count
+ *           (> shard_capacity: records were dropped -- grow and scan again), records present behind the header
+ *           = min(valid, packed_capacity), shard_capacity}, then that many WbDet records (shard order)
+ * One contiguous prefix for a single host read-back (Model.detect, model.py:173-179) or one collective
+ * (multi-GPU gather of detections); no host synchronisation. */
+int wb_det_pack_launch(void *stream, const WbDet *det, const uint32_t *det_count, uint32_t shard_capacity,
+                       int32_t *packed, uint32_t packed_capacity);
 
 /* One tree evaluated at explicit window origins (rs[i], cs[i]) of an HWC channel image
  * X[u][v][C] of x_dtype (WB_DTYPE_F32 / WB_DTYPE_U8); out[i] = prediction of the leaf reached

@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from waldboost_amd import _native as nat
-from waldboost_amd.distributed import DetectionGatherer, shard_range
+from waldboost_amd.distributed import DetectionGatherer, agree_capacity, gather_records, reduce_alive, shard_range
 from waldboost_amd.engine import DetBuffer
 
 
@@ -104,3 +104,77 @@ def test_overflowing_shard_is_reported():
             self.recv = detb.buf.clone()
     with pytest.raises(OverflowError):
         G(detb).merged([1])
+
+
+# ------------------------------------------------------------------------------ the end-of-batch exchange
+class _FakeScan:
+    """A rank's scan state as agree_capacity sees it: `true_need` records would land in the fullest shard."""
+
+    def __init__(self, cap, true_need):
+        self.cap, self.true_need, self.grown = cap, true_need, []
+
+    def need(self):
+        return self.true_need
+
+    def grow(self, cap):
+        self.grown.append(cap)
+        self.cap = cap
+
+
+def _exchange_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # (1) only rank 1 overflows: both ranks must end with the same capacity, in the same number of rounds
+        scan = _FakeScan(cap=32, true_need=[20, 75][rank])
+        rounds = agree_capacity(scan)
+        # (2) unequal starting capacities, nobody overflows: the smaller one grows to the larger
+        scan2 = _FakeScan(cap=[64, 16][rank], true_need=[10, 12][rank])
+        rounds2 = agree_capacity(scan2)
+        # (3) nothing to do
+        scan3 = _FakeScan(cap=32, true_need=[0, 31][rank])
+        rounds3 = agree_capacity(scan3)
+        # (4) valid prefixes of different lengths (one rank may have none) to rank 0, alive summed everywhere
+        recs = _fake_detections(rank, [3, 2][rank])
+        if rank == 0:
+            recs = recs[:0]
+        det = gather_records(torch.from_numpy(recs.view(np.int32).reshape(-1, 4).copy()), [3, 2][rank], dst=0)
+        alive = np.arange(12, dtype=np.int64).reshape(3, 4) * (rank + 1)
+        tot = reduce_alive(alive)
+        q.put((rank, dict(cap=scan.cap, grown=scan.grown, rounds=rounds, cap2=scan2.cap, rounds2=rounds2,
+                          cap3=scan3.cap, rounds3=rounds3, grown3=scan3.grown,
+                          det=None if det is None else det.tobytes(), tot=tot.tolist())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_capacity_agreement_prefix_gather_and_alive_reduce_world_size_2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = out[0], out[1]
+    # (1) rank 0 did not overflow but grows with rank 1, to the same size, after the same single round
+    assert a["cap"] == b["cap"] == int(75 * 1.5) + 16 and a["rounds"] == b["rounds"] == 1
+    assert a["grown"] == b["grown"] == [a["cap"]]
+    # (2) capacities equalised without a rescan on the rank that was large enough
+    assert a["cap2"] == b["cap2"] == 64 and a["rounds2"] == b["rounds2"] == 1
+    # (3) no growth at all
+    assert a["cap3"] == b["cap3"] == 32 and a["rounds3"] == b["rounds3"] == 0 and a["grown3"] == b["grown3"] == []
+    # (4) rank 0 holds rank 1's records with global image indices (rank 0 scanned 3 images, found nothing)
+    assert b["det"] is None
+    got = np.frombuffer(a["det"], nat.DET_DTYPE)
+    want = _fake_detections(1, 2)
+    want["image"] += 3
+    want = want[np.lexsort((want["c"], want["r"], want["level"], want["image"]))]
+    assert np.array_equal(np.stack([got[k].astype(np.int64) for k in ("image", "level", "r", "c")]),
+                          np.stack([want[k].astype(np.int64) for k in ("image", "level", "r", "c")]))
+    assert sorted(got["score"].tolist()) == sorted(want["score"].tolist())
+    assert a["tot"] == b["tot"] == (np.arange(12).reshape(3, 4) * 3).tolist()

@@ -90,7 +90,7 @@ def test_pyramid_and_cascade_through_the_raw_abi():
                                        C.c_int(0), C.c_int(1), P(levels_d.data_ptr()), C.c_int(plan.n_levels), P(ctiles_d.data_ptr()),
                                        C.c_int(ctiles.size), P(minmax.data_ptr()), C.c_int(plan.n_oct), P(taps_d.data_ptr()),
                                        C.c_int(0), C.c_int(2), C.c_int(1), cs_sn.ctypes.data_as(C.POINTER(C.c_double)),
-                                       P(chn.data_ptr()), C.c_int64(chn_total)))
+                                       P(chn.data_ptr()), C.c_int64(chn_total), None, None, C.c_int64(0)))
     tiles = plan.casc_tiles(12, 12, info.tile_rows, info.tile_cols)
     csr = plan.tile_csr(tiles, plan.n_levels)
     tiles_d, csr_d = up(tiles), torch.from_numpy(csr).to(dev)
@@ -109,6 +109,29 @@ def test_pyramid_and_cascade_through_the_raw_abi():
     assert np.array_equal(d["level"], ref["level"]) and np.array_equal(d["r"], ref["r"]) and np.array_equal(d["c"], ref["c"])
     assert np.array_equal(d["score"].view(np.uint32), ref["scores"].view(np.uint32))
     assert np.array_equal(alive.cpu().numpy()[0].astype(np.int64), ref["alive"])
+    # the same scan on WB_DTYPE_RANK8 channels: the channel kernel writes ranks only (chn = NULL), the cascade reads
+    # them with chn_dtype = 2; then the packed read-back form (wb_det_pack_launch)
+    assert info.rank_ok == 1
+    rank = torch.zeros(chn_total + 16, dtype=torch.uint8, device=dev)
+    _check(lib, lib.wb_channels_launch(st, P(img_d.data_ptr()), C.c_int64(H * W), P(oct_d.data_ptr()), C.c_int64(plan.oct_total),
+                                       C.c_int(0), C.c_int(1), P(levels_d.data_ptr()), C.c_int(plan.n_levels), P(ctiles_d.data_ptr()),
+                                       C.c_int(ctiles.size), P(minmax.data_ptr()), C.c_int(plan.n_oct), P(taps_d.data_ptr()),
+                                       C.c_int(0), C.c_int(2), C.c_int(1), cs_sn.ctypes.data_as(C.POINTER(C.c_double)),
+                                       None, C.c_int64(chn_total), h, P(rank.data_ptr()), C.c_int64(chn_total)))
+    det2 = torch.zeros((16 + 64 * cap, 4), dtype=torch.int32, device=dev)
+    alive2 = torch.empty((1, plan.n_levels, T), dtype=torch.int32, device=dev)
+    _check(lib, lib.wb_cascade_launch(st, h, P(rank.data_ptr()), C.c_int(2), C.c_int64(chn_total), C.c_int(1), P(levels_d.data_ptr()),
+                                      C.c_int(plan.n_levels), P(tiles_d.data_ptr()), P(csr_d.data_ptr()), C.c_int(tiles.size),
+                                      P(det2[16:].data_ptr()), P(det2.data_ptr()), C.c_uint32(cap), P(hist.data_ptr()), P(alive2.data_ptr())))
+    packed = torch.zeros((1 + 64 * cap, 4), dtype=torch.int32, device=dev)
+    _check(lib, lib.wb_det_pack_launch(st, P(det2[16:].data_ptr()), P(det2.data_ptr()), C.c_uint32(cap), P(packed.data_ptr()),
+                                       C.c_uint32(64 * cap)))
+    torch.cuda.synchronize()
+    pk = packed.cpu().numpy()
+    assert pk[0].tolist() == [d.size, int(det2[:16].max()), d.size, cap]
+    d2 = pk[1:1 + d.size].copy().view(nat.DET_DTYPE).reshape(-1)
+    d2 = d2[np.lexsort((d2["c"], d2["r"], d2["level"]))]
+    assert np.array_equal(d2, d) and np.array_equal(alive2.cpu().numpy(), alive.cpu().numpy())
     # boxes
     inv = torch.from_numpy(np.array([np.float32(1.0 / s) for s in plan.scales], np.float32)).to(dev)
     recs = torch.from_numpy(d.view(np.int32).reshape(-1, 4).copy()).to(dev)

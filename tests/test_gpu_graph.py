@@ -1,0 +1,97 @@
+"""Parity of the path bench.py times: hipGraph replay of octaves -> channels -> cascade over resident
+batches, several graphs in flight on separate streams, images replaced between replays.
+
+Every image of every replay is compared with the oracle (reference model.py:149-179 per image):
+detections (level, r, c, score bits) and alive[level, stage], bit-exact.  Also BASELINE configs[2]
+at its full size (64 x 1080p in one launch per kernel)."""
+import os
+
+import numpy as np
+import pytest
+
+import waldboost_amd as wb
+from waldboost_amd import _native as nat
+from waldboost_amd.synth import synth_image
+from util import GOLDEN, oracle_detect
+
+pytestmark = pytest.mark.gpu
+
+MODELS = {"grad_hist": "cfg2_d2_T128.pb", "grad_hist_4_u1": "cfg2_gh4u1_d2_T128.pb"}
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def engine_results(e, stt, T):
+    """Per image (level, r, c, score) in reference order + alive[level, stage] of the engine's last scan."""
+    d = e.sorted_detections().cpu().numpy().view(nat.DET_DTYPE).reshape(-1)
+    alive = stt["alive"][:, :, :T].cpu().numpy().astype(np.int64)
+    assert int(e.detb.counts.max().item()) <= e.detb.cap
+    return [(d[d["image"] == b], alive[b]) for b in range(e.batch)]
+
+
+def assert_image_matches(got, ref):
+    d, alive = got
+    assert np.array_equal(alive, ref["alive"])
+    assert np.array_equal(d["level"], ref["level"]) and np.array_equal(d["r"], ref["r"]) and np.array_equal(d["c"], ref["c"])
+    assert np.array_equal(bits(d["score"]), bits(ref["scores"]))
+
+
+@pytest.mark.parametrize("channels", sorted(MODELS))
+@pytest.mark.parametrize("shape,B", [((1080, 1920), 1), ((300, 420), 3)])
+def test_graph_replay_on_two_streams_with_new_images_vs_oracle(channels, shape, B):
+    import torch
+    from waldboost_amd.engine import PyramidEngine
+    M = wb.load(os.path.join(GOLDEN, "models", MODELS[channels]))
+    spec = wb.channels.channel_spec(M.channel_opts["channels"])
+    dm = M.device_cascade()
+    H, W = shape
+    P = 2
+    engines = [PyramidEngine(H, W, np.uint8, 2, 8, 1, batch=B, det_capacity=16384 * B, channels=spec) for _ in range(P)]
+    seed = lambda rnd, i, b: 5000 + 100 * rnd + 10 * i + b
+    for i, e in enumerate(engines):
+        e.load_images(np.stack([synth_image(H, W, seed(0, i, b)) for b in range(B)]))
+    graphs = [e.capture(dm) for e in engines]
+    lanes = [torch.cuda.Stream() for _ in range(P)]
+    oracle = {}
+    for rnd in range(2):
+        if rnd:                                     # new images into the resident buffers, then replay the same graphs
+            for i, e in enumerate(engines):
+                e.load_images(np.stack([synth_image(H, W, seed(rnd, i, b)) for b in range(B)]))
+        torch.cuda.synchronize()
+        for _ in range(3):                          # replays overlap across the two streams, as in bench.py
+            for i in range(P):
+                with torch.cuda.stream(lanes[i]):
+                    graphs[i].replay()
+        torch.cuda.synchronize()
+        for i, e in enumerate(engines):
+            res = engine_results(e, e._casc_state(dm), len(M))
+            for b in range(B):
+                s = seed(rnd, i, b)
+                if s not in oracle:
+                    oracle[s] = oracle_detect(M, synth_image(H, W, s))
+                assert_image_matches(res[b], oracle[s])
+    assert sum(o["scores"].size for o in oracle.values()) > 0
+
+
+def test_config3_batch_of_64_1080p_images():
+    """BASELINE configs[2] at full size: 64 x 1920x1080 in one launch per kernel.  Images 0, 31 and 63
+    against the oracle, the rest through the batch properties (sorted output, statistics add up)."""
+    M = wb.load(os.path.join(GOLDEN, "models", "cfg2_d2_T128.pb"))
+    B = 64
+    imgs = np.stack([synth_image(1080, 1920, 2000 + b) for b in range(B)])
+    res = M.detect_batch_raw(imgs)
+    assert M.n_loc == B * 3045278
+    key = np.stack([res["image"], res["level"], res["r"], res["c"]], 1).astype(np.int64)
+    assert np.array_equal(np.lexsort((key[:, 3], key[:, 2], key[:, 1], key[:, 0])), np.arange(key.shape[0]))
+    alive = res["alive"]
+    assert alive[:, :, 0].sum() == M.n_loc and alive.sum() == M.n_weak and (np.diff(alive, axis=2) <= 0).all()
+    assert np.bincount(res["image"], minlength=B).min() > 0
+    for b in (0, 31, 63):
+        ref = oracle_detect(M, imgs[b])
+        sel = res["image"] == b
+        assert np.array_equal(alive[b], ref["alive"])
+        assert np.array_equal(res["level"][sel], ref["level"]) and np.array_equal(res["r"][sel], ref["r"])
+        assert np.array_equal(res["c"][sel], ref["c"]) and np.array_equal(bits(res["scores"][sel]), bits(ref["scores"]))
+        assert np.array_equal(bits(res["boxes"][sel]), bits(ref["boxes"]))

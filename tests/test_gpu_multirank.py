@@ -19,13 +19,21 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import waldboost_amd as wb
-        from waldboost_amd.distributed import detect_sharded
+        from waldboost_amd import engine as _engine
+        from waldboost_amd.distributed import detect_sharded, shard_range
         from waldboost_amd.synth import synth_image
         here = os.path.dirname(os.path.abspath(__file__))
         M = wb.load(os.path.join(here, "golden", "mixed_d2_T24.pb"))
-        imgs = np.stack([synth_image(200, 264, 900 + b) for b in range(5)])
-        det, alive = detect_sharded(M, imgs)
-        q.put((rank, det.tobytes(), alive.shape))
+        lo, hi = shard_range(5, rank, world)
+        imgs = np.stack([synth_image(200, 264, 900 + b) for b in range(lo, hi)])      # this rank's shard only
+        if rank == 1:
+            # rank 1 starts with a detection buffer that is too small: both ranks must grow together
+            eng = _engine.get_engine(200, 264, np.uint8, 2, 8, 1, hi - lo)
+            eng.det_capacity = 16
+            eng._alloc_det()
+        det, alive, total = detect_sharded(M, imgs)
+        caps = [e.detb.cap for e in _engine._ENGINES.values()]
+        q.put((rank, None if det is None else det.tobytes(), alive.shape, total.tolist(), (M.n_loc, M.n_weak), caps))
     finally:
         dist.destroy_process_group()
 
@@ -42,16 +50,20 @@ def test_detect_sharded_two_ranks_one_gpu():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    out = dict((r, (d, sh)) for r, d, sh in (q.get(timeout=300) for _ in range(2)))
+    out = dict((r, rest) for r, *rest in (q.get(timeout=300) for _ in range(2)))
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
     M = wb.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mixed_d2_T24.pb"))
     imgs = np.stack([synth_image(200, 264, 900 + b) for b in range(5)])
     ref = M.detect_batch_raw(imgs)
-    for r in range(2):
-        got = np.frombuffer(out[r][0], nat.DET_DTYPE)
-        assert np.array_equal(got["image"], ref["image"]) and np.array_equal(got["level"], ref["level"])
-        assert np.array_equal(got["r"], ref["r"].astype(np.uint16)) and np.array_equal(got["c"], ref["c"].astype(np.uint16))
-        assert np.array_equal(got["score"].view(np.uint32), ref["scores"].view(np.uint32))
+    assert out[1][0] is None                                # the records go to rank 0 only
+    got = np.frombuffer(out[0][0], nat.DET_DTYPE)
+    assert np.array_equal(got["image"], ref["image"]) and np.array_equal(got["level"], ref["level"])
+    assert np.array_equal(got["r"], ref["r"].astype(np.uint16)) and np.array_equal(got["c"], ref["c"].astype(np.uint16))
+    assert np.array_equal(got["score"].view(np.uint32), ref["scores"].view(np.uint32))
     assert out[0][1][0] == 3 and out[1][1][0] == 2          # shard sizes 3 + 2
+    for r in range(2):                                      # the summed statistics, on every rank
+        assert np.array_equal(np.array(out[r][2]), ref["alive"].sum(axis=0))
+        assert out[r][3] == (M.n_loc, M.n_weak)
+    assert out[0][4] == out[1][4] and out[1][4][0] > 16     # rank 1 overflowed; both ranks grew to the same capacity

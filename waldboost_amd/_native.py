@@ -13,11 +13,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # WB_NATIVE_LIB: A/B timing of two builds of the same ABI in one session (diagnostic)
 LIB_PATH = os.environ.get("WB_NATIVE_LIB") or os.path.join(_HERE, "csrc", "libwaldboost_hip.so")
 
-WB_DTYPE_U8, WB_DTYPE_F32 = 0, 1
+WB_DTYPE_U8, WB_DTYPE_F32, WB_DTYPE_RANK8 = 0, 1, 2
 WB_ERR_INVALID, WB_ERR_HIP, WB_ERR_UNSUPPORTED = -1, -2, -3
 WB_DET_SHARDS = 64
 WB_CHN_GRAD_HIST, WB_CHN_GRAD_HIST_4_U1, WB_CHN_GRAD_MAG_U1, WB_CHN_GRAD_MAG = 0, 1, 2, 3
-WB_ABI_VERSION = 2
+WB_ABI_VERSION = 3
 
 # numpy mirrors of the ABI structs (sizes asserted against the header's comments)
 LEVEL_DTYPE = np.dtype([
@@ -32,7 +32,8 @@ assert LEVEL_DTYPE.itemsize == 64 and TILE_DTYPE.itemsize == 8 and DET_DTYPE.ite
 
 class WbModelInfo(C.Structure):
     _fields_ = [("n_stages", C.c_int32), ("depth", C.c_int32), ("m", C.c_int32), ("n", C.c_int32),
-                ("C", C.c_int32), ("tile_rows", C.c_int32), ("tile_cols", C.c_int32), ("lds_bytes", C.c_int32)]
+                ("C", C.c_int32), ("tile_rows", C.c_int32), ("tile_cols", C.c_int32), ("lds_bytes", C.c_int32),
+                ("rank_ok", C.c_int32)]
 
 
 # every symbol include/waldboost_hip.h declares: name -> (restype, argtypes)
@@ -45,7 +46,8 @@ SYMBOLS = {
     "wb_octaves_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, C.c_int64,
                                     C.POINTER(C.c_int64), C.c_int, _P]),
     "wb_channels_launch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int,
-                                     _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P, C.c_int64]),
+                                     _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P, C.c_int64,
+                                     _P, _P, C.c_int64]),
     "wb_model_create": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "wb_model_destroy": (C.c_int, [_P]),
     "wb_model_info": (C.c_int, [_P, C.POINTER(WbModelInfo)]),
@@ -57,6 +59,7 @@ SYMBOLS = {
     "wb_samples_predict_launch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P]),
     "wb_tree_apply_launch": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "wb_boxes_launch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int, C.c_int, _P, _P]),
+    "wb_det_pack_launch": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32]),
     "wb_selftest_projection": (C.c_int, [_P, _P]),
 }
 

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "wb_common.h"
@@ -31,7 +32,17 @@ struct TreeView {
     const float *threshold;
     const int8_t *left, *right;
     const float *prediction;
+    const int32_t *rank;   // binned tiles: index of the node's threshold among its channel's sorted distinct thresholds (-1: NaN)
 };
+
+// cell of the linear lookup grid a value falls into -- the host mirror of bin_cell() in wb_cascade.hip
+// (fmaf is correctly rounded on both sides, so both map every float to the same cell)
+inline uint32_t bin_cell(float v, float k, float b, int N) {
+    const float q = fmaf(v, k, b);
+    if (!(q > 0.0f)) return 0u;
+    if (q >= (float)(N - 1)) return (uint32_t)(N - 1);
+    return (uint32_t)q;
+}
 
 int tree_depth(const TreeView &t, int node) {
     if (t.left[node] < 0) return 0;
@@ -45,7 +56,8 @@ int tree_depth(const TreeView &t, int node) {
 // BYTES: records for uint8 channels -- offsets address the interleaved byte tile [row][col][C], thresholds are
 // integers (stored in the float slots): for an integer pixel v, `v <= thr` is `v <= floor(thr)`; a NaN or negative
 // threshold is never met (-1), anything from 255 up always (255).
-template <bool BYTES>
+// BYTES == 2: the byte tile holds threshold ranks of float32 pixels (WbModel::bin_*): the integer is the node's rank.
+template <int BYTES>
 void fill(const TreeView &t, int node, int ci, int d, int D, int rows, int pitch, int C, int32_t *off, float *thr,
           float *pred) {
     const int NI = (1 << D) - 1;
@@ -65,6 +77,7 @@ void fill(const TreeView &t, int node, int ci, int d, int D, int rows, int pitch
         off[ci] = (fr * pitch + fc) * C + ch;
         const float th = t.threshold[node];
         int32_t ti = !(th >= 0.0f) ? -1 : (th >= 255.0f ? 255 : (int32_t)floorf(th));
+        if (BYTES == 2) ti = t.rank[node];
         memcpy(&thr[ci], &ti, 4);
     } else {
         off[ci] = ((ch * rows + fr) * pitch + fc) * 4;   // byte offset inside the LDS tile
@@ -94,7 +107,7 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
     for (int s = 0; s < n_stages; ++s) {
         int o = node_off[s], k = node_off[s + 1] - node_off[s];
         WB_REQUIRE(o >= 0 && k >= 1 && k <= 127, "wb_model_create: stage %d has %d nodes (1..127 allowed: int8 links)", s, k);
-        TreeView t{k, feature + (size_t)o * 3, threshold + o, left + o, right + o, prediction + o};
+        TreeView t{k, feature + (size_t)o * 3, threshold + o, left + o, right + o, prediction + o, nullptr};
         for (int i = 0; i < k; ++i) {
             if (t.left[i] < 0) continue;
             WB_REQUIRE(t.left[i] > i && t.left[i] < k && t.right[i] > i && t.right[i] < k,
@@ -188,33 +201,106 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         return WB_OK;
     }
 
+    // ---- rank tables for float32 channels (wb_common.h: WbModel::bin_*): sorted distinct thresholds per channel
+    std::vector<int32_t> rank((size_t)(n_stages ? node_off[n_stages] : 0), -1);
+    std::vector<uint8_t> lut;
+    {
+        const int N = WB_BIN_CELLS;
+        bool ok = C == 4 && n_stages > 0 && getenv("WB_NO_RANKS") == nullptr;
+        std::vector<float> S[4];
+        if (ok) {
+            for (int s = 0; s < n_stages; ++s)
+                for (int i = 0; i < trees[s].k; ++i)
+                    if (trees[s].left[i] >= 0 && trees[s].threshold[i] == trees[s].threshold[i])
+                        S[trees[s].feature[i * 3 + 2]].push_back(trees[s].threshold[i]);
+            for (int c = 0; c < 4 && ok; ++c) {
+                std::sort(S[c].begin(), S[c].end());
+                S[c].erase(std::unique(S[c].begin(), S[c].end()), S[c].end());     // (== merges -0.0 and 0.0)
+                ok = (int)S[c].size() <= WB_BIN_MAX;
+            }
+        }
+        int K = 1;
+        if (ok) {
+            lut.assign((size_t)4 * WB_BIN_SLOTS * 4 + (size_t)4 * N, 0);
+            float *Stab = reinterpret_cast<float *>(lut.data());
+            uint8_t *base = lut.data() + 4 * WB_BIN_SLOTS * 4;
+            for (int c = 0; c < 4 && ok; ++c) {
+                float lo = INFINITY, hi = -INFINITY;
+                for (float v : S[c])
+                    if (isfinite(v)) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
+                double k = 1.0, b = 1.0;
+                if (hi > lo) k = (double)(N - 2) / ((double)hi - (double)lo);
+                if (lo <= hi) b = 1.0 - (double)lo * k;
+                M->bin_k[c] = (float)k;
+                M->bin_b[c] = (float)b;
+                ok = isfinite(M->bin_k[c]) && isfinite(M->bin_b[c]) && M->bin_k[c] > 0.0f;
+                if (!ok) break;
+                std::vector<int> cnt((size_t)N, 0);
+                for (float v : S[c]) cnt[bin_cell(v, M->bin_k[c], M->bin_b[c], N)]++;    // non-decreasing in v
+                int run = 0;
+                for (int j = 0; j < N; ++j) {
+                    base[(size_t)c * N + j] = (uint8_t)run;
+                    run += cnt[j];
+                    if (cnt[j] > K) K = cnt[j];
+                }
+                for (int j = 0; j < WB_BIN_SLOTS; ++j) Stab[c * WB_BIN_SLOTS + j] = j < (int)S[c].size() ? S[c][j] : INFINITY;
+            }
+            ok = ok && K <= 16;
+        }
+        if (ok) {
+            for (int s = 0; s < n_stages; ++s) {
+                for (int i = 0; i < trees[s].k; ++i) {
+                    const float th = trees[s].threshold[i];
+                    if (trees[s].left[i] < 0 || th != th) continue;
+                    const std::vector<float> &v = S[trees[s].feature[i * 3 + 2]];
+                    rank[(size_t)node_off[s] + i] = (int32_t)(std::lower_bound(v.begin(), v.end(), th) - v.begin());
+                }
+                trees[s].rank = rank.data() + node_off[s];
+            }
+            M->bin_ok = 1;
+            M->bin_cells = N;
+            M->bin_iters = K;
+            M->bin_lut_vec = (int)(lut.size() / 16);
+        }
+    }
+
     // ---- pack and upload the stage records
     const int NI = (1 << D) - 1, NL = 1 << D, SD = M->stage_dwords;
     // G trailing no-op records (offset 0, prediction 0, theta -inf) so a group load never leaves the table
     const int G = wb_cascade_group(D);
-    std::vector<int32_t> packed((size_t)(n_stages + G) * SD, 0), packed8((size_t)(n_stages + G) * SD, 0);
-    for (int s = n_stages; s < n_stages + G; ++s) {
-        reinterpret_cast<float *>(packed.data() + (size_t)s * SD)[2 * NI + NL] = -INFINITY;
-        reinterpret_cast<float *>(packed8.data() + (size_t)s * SD)[2 * NI + NL] = -INFINITY;
-    }
-    for (int s = 0; s < n_stages; ++s) {
-        for (int bytes = 0; bytes < 2; ++bytes) {
-            int32_t *rec = (bytes ? packed8 : packed).data() + (size_t)s * SD;
+    std::vector<int32_t> packs[3];
+    for (int mode = 0; mode < 3; ++mode) {
+        std::vector<int32_t> &packed = packs[mode];
+        packed.assign((size_t)(n_stages + G) * SD, 0);
+        for (int s = n_stages; s < n_stages + G; ++s)
+            reinterpret_cast<float *>(packed.data() + (size_t)s * SD)[2 * NI + NL] = -INFINITY;
+        if (mode == 2 && !M->bin_ok) continue;
+        for (int s = 0; s < n_stages; ++s) {
+            int32_t *rec = packed.data() + (size_t)s * SD;
             int32_t *off = rec;
             float *thr = reinterpret_cast<float *>(rec + NI);
             float *pred = reinterpret_cast<float *>(rec + 2 * NI);
-            if (bytes)
-                fill<true>(trees[s], 0, 0, 0, D, M->lds_rows, M->lds_pitch, C, off, thr, pred);
+            if (mode == 2)
+                fill<2>(trees[s], 0, 0, 0, D, M->lds_rows, M->lds_pitch, C, off, thr, pred);
+            else if (mode == 1)
+                fill<1>(trees[s], 0, 0, 0, D, M->lds_rows, M->lds_pitch, C, off, thr, pred);
             else
-                fill<false>(trees[s], 0, 0, 0, D, M->lds_rows, M->lds_pitch, C, off, thr, pred);
+                fill<0>(trees[s], 0, 0, 0, D, M->lds_rows, M->lds_pitch, C, off, thr, pred);
             reinterpret_cast<float *>(rec)[2 * NI + NL] = theta[s];
         }
     }
     {
+        const std::vector<int32_t> &packed = packs[0];
         hipError_t e = hipMalloc((void **)&M->stages_dev, packed.size() * 4);
         if (e == hipSuccess) e = hipMemcpy(M->stages_dev, packed.data(), packed.size() * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc((void **)&M->stages_u8_dev, packed8.size() * 4);
-        if (e == hipSuccess) e = hipMemcpy(M->stages_u8_dev, packed8.data(), packed8.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void **)&M->stages_u8_dev, packs[1].size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(M->stages_u8_dev, packs[1].data(), packs[1].size() * 4, hipMemcpyHostToDevice);
+        if (M->bin_ok) {
+            if (e == hipSuccess) e = hipMalloc((void **)&M->stages_bin_dev, packs[2].size() * 4);
+            if (e == hipSuccess) e = hipMemcpy(M->stages_bin_dev, packs[2].data(), packs[2].size() * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void **)&M->bin_lut_dev, lut.size());
+            if (e == hipSuccess) e = hipMemcpy(M->bin_lut_dev, lut.data(), lut.size(), hipMemcpyHostToDevice);
+        }
         if (e != hipSuccess) {
             wb_set_error("wb_model_create: uploading %zu stage bytes failed: %s", packed.size() * 4, hipGetErrorString(e));
             wb_model_destroy(M);
@@ -234,6 +320,8 @@ extern "C" int wb_model_destroy(WbModel *model) {
     if (!model) return WB_OK;
     if (model->stages_dev) (void)hipFree(model->stages_dev);
     if (model->stages_u8_dev) (void)hipFree(model->stages_u8_dev);
+    if (model->stages_bin_dev) (void)hipFree(model->stages_bin_dev);
+    if (model->bin_lut_dev) (void)hipFree(model->bin_lut_dev);
     void *g[] = {model->g_node_off, model->g_feat, model->g_thr, model->g_left, model->g_right, model->g_pred, model->g_theta};
     for (void *p : g)
         if (p) (void)hipFree(p);
@@ -251,5 +339,6 @@ extern "C" int wb_model_info(const WbModel *model, WbModelInfo *info) {
     info->tile_rows = model->tile_rows;
     info->tile_cols = WB_CASC_TC;
     info->lds_bytes = model->lds_bytes;
+    info->rank_ok = model->bin_ok;
     return WB_OK;
 }

@@ -55,6 +55,7 @@ struct CascArgs {
     uint32_t *alive;            // [batch][n_levels][T] written by the reduction kernel
     const int32_t *tile_csr;    // [n_levels + 1] starts, then [n_tiles] tile indices grouped by level
     int n_tiles;
+    int spar_wg;                // the whole tile goes stage-parallel after phase A when it holds at most this many windows
     int spar[4];                // stage-parallel tail entry: (t >= spar[0] && n <= spar[1]) || (t >= spar[2] && n <= spar[3])
     int dbg;                    // diagnostics (WB_CASC_DBG): 1 = skip the tile load, 2 = stop after the load
 };
@@ -152,8 +153,11 @@ __device__ inline int lane_rank(unsigned long long mask) {
 // at any stage < T.
 template <int D> struct GroupSize { static constexpr int G = (D >= 3) ? 2 : 4; };
 
+// U8: the channels are bytes -- uint8 channels as the reference's integer channel functions produce them, or the
+// threshold RANKS of float32 channels (wb_channels_launch with a rank model; the stage records then carry the
+// thresholds' indices): the tile is the pixels as they are, a quarter of the float tile.
 template <int D, int RPW, int WAVES, bool U8>
-__global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, const int32_t *__restrict__ stages) {
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) void cascade_tile_kernel(CascArgs a, const int32_t *__restrict__ stages) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t wcnt[WAVES];
     __shared__ uint32_t wg_base;
@@ -368,12 +372,26 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         }
     }
     int n_q = my_cnt;
+    int qs = 1;                                                   // stride of this wave's queue entries
+    bool scatter = false;
     if (T > S0) {
         __syncthreads();                                          // pooled entries visible; wcnt free again
         if (pooled) {
-            queue = wgq + 64 * wave;
-            int left = (int)total - 64 * wave;
-            n_q = left < 0 ? 0 : (left > 64 ? 64 : left);
+            // Few survivors in the whole tile (the usual case for a rejecting cascade: a few dozen of 2048):
+            // deal them out one by one to ALL waves, which take them straight to the stage-parallel evaluator
+            // below -- every wave works, instead of one or two waves walking ~100 stages in groups of G while
+            // the others wait at the final barrier.  Many survivors: whole chunks of 64 per wave, as dense
+            // wave-synchronous segments.
+            scatter = total <= (uint32_t)a.spar_wg;
+            if (scatter) {
+                queue = wgq + wave;
+                qs = WAVES;
+                n_q = (int)total > wave ? ((int)total - wave + WAVES - 1) / WAVES : 0;
+            } else {
+                queue = wgq + 64 * wave;
+                int left = (int)total - 64 * wave;
+                n_q = left < 0 ? 0 : (left > 64 ? 64 : left);
+            }
         }
     }
     WB_STAMP(2);
@@ -431,7 +449,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
 
     static_assert(S0 == 8, "the pooling above assumes phase A ends at stage 8");
     if (a.dbg & 8) return;
-    run_segments(T);
+    if (!scatter) run_segments(T);
     WB_STAMP(4);
     if (a.dbg & 16) return;
 
@@ -459,8 +477,9 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
             st.load(rec);
         }
         int n_out = 0;
+        uint32_t entered_t = 0;                                  // windows that entered stage rs + lane in this pass
         for (int i = 0; i < n_q; ++i) {
-            const uint2 e = queue[i];                            // same entry in every lane
+            const uint2 e = queue[i * qs];                       // same entry in every lane
             const int pos = (int)e.x;
             const int wbase = ((pos >> 6) * pitch + (pos & 63)) * px_stride;
             const float p = st.template eval<U8>(tile, wbase);
@@ -468,29 +487,38 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
             // additions in the same order as the reference's running `hs +=` -- so it ends up
             // with the score the rejection test of stage rs+k sees.
             // (ripple through the wave with DPP wave_shr:1 -- lane k takes lane k-1's running sum
-            // and adds its own p; after step k+1 lane k is final and later steps recompute the
-            // same value, so 64 steps settle every lane)
+            // and adds its own p; after step j lanes 0..j are final and later steps recompute the
+            // same value, so 63 steps settle every lane)
             // Lane 0 folds the incoming score into its addend (0 + x == x exactly), so the shifted-in
             // value of the out-of-range lane can be the DPP zero (bound_ctrl) and each step is ONE
             // v_add_f32 with a wave_shr:1 source.
+            // Most windows are rejected within a few stages, so the ripple runs in blocks of 8 steps and stops
+            // at the first block whose settled lanes hold a rejection: the lowest such lane is the first
+            // rejecting stage (every earlier stage is settled and passed).
             const float h_in = __uint_as_float(e.y);
             const float pk = lane == 0 ? h_in + p : p;
             float hk = pk;
+            unsigned long long rmask;
+            for (int settled = 1;;) {                            // lanes [0, settled) hold their final sums
 #pragma unroll
-            for (int j = 0; j < 63; ++j) {
-                int prev = __builtin_amdgcn_update_dpp(0, __float_as_int(hk), 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-                hk = __int_as_float(prev) + pk;
+                for (int j = 0; j < 8; ++j) {
+                    int prev = __builtin_amdgcn_update_dpp(0, __float_as_int(hk), 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+                    hk = __int_as_float(prev) + pk;
+                }
+                settled += 8;
+                const int upto = settled < nvalid ? settled : nvalid;
+                rmask = __ballot((lane < upto) && (st.theta != -INFINITY) && !(hk >= st.theta));
+                if (rmask || settled >= nvalid) break;
             }
-            const bool rej = (lane < nvalid) && (st.theta != -INFINITY) && !(hk >= st.theta);
-            const unsigned long long rmask = __ballot(rej);
             const int last = rmask ? (int)__builtin_ctzll(rmask) : nvalid - 1;   // last stage entered
-            if (lane <= last) atomicAdd(&hist[t], 1u);
+            entered_t += lane <= last ? 1u : 0u;
             if (!rmask) {
                 float hl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hk), nvalid - 1));
-                if (lane == 0) queue[n_out] = make_uint2((uint32_t)pos, __float_as_uint(hl));   // n_out <= i
+                if (lane == 0) queue[n_out * qs] = make_uint2((uint32_t)pos, __float_as_uint(hl));   // n_out <= i
                 ++n_out;
             }
         }
+        if (entered_t) atomicAdd(&hist[t], entered_t);           // (lanes >= nvalid never count: last < nvalid)
         n_q = n_out;
     }
 
@@ -518,7 +546,7 @@ __global__ __launch_bounds__(WAVES * 64) void cascade_tile_kernel(CascArgs a, co
         for (int w = 0; w < wave; ++w) o += wcnt[w];
         WbDet *dst = a.det + (size_t)shard * a.det_cap;
         for (int i = lane; i < n_q; i += 64) {
-            uint2 e = queue[i];
+            uint2 e = queue[i * qs];
             if (o + i < a.det_cap) {
                 WbDet d;
                 d.image = b;
@@ -747,6 +775,37 @@ __global__ void boxes_kernel(const WbDet *det, int64_t n_det, const float *inv_s
     scores[i] = d.score;
 }
 
+// The valid records of all detection shards, back to back behind a 4-word header -- what a host read-back or a
+// collective wants: ONE contiguous prefix whose length the header gives.  One workgroup per shard; every workgroup
+// reads all WB_DET_SHARDS counters (256 B) and derives its own output offset, so there is no second pass.
+__global__ __launch_bounds__(256) void det_pack_kernel(const WbDet *det, const uint32_t *det_count, uint32_t cap,
+                                                        int32_t *out, uint32_t out_cap) {
+    static_assert(WB_DET_SHARDS == 64, "one counter per lane of a wave");
+    const int shard = blockIdx.x, lane = threadIdx.x & 63;
+    const uint32_t raw = det_count[lane];
+    const uint32_t mine = raw < cap ? raw : cap;
+    uint32_t before = 0, total = 0, worst = 0;
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)mine, s);
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)raw, s);
+        before += s < shard ? c : 0u;
+        total += c;
+        worst = r > worst ? r : worst;
+    }
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)mine, shard);
+    if (shard == 0 && threadIdx.x == 0) {
+        out[0] = (int32_t)total;                              // valid records in all shards
+        out[1] = (int32_t)worst;                              // fullest shard (> cap: records were dropped, scan again)
+        out[2] = (int32_t)(total < out_cap ? total : out_cap);  // records present behind this header
+        out[3] = (int32_t)cap;
+    }
+    const uint4 *src = reinterpret_cast<const uint4 *>(det + (size_t)shard * cap);
+    uint4 *dst = reinterpret_cast<uint4 *>(out) + 1;
+    for (uint32_t i = threadIdx.x; i < n; i += 256)
+        if (before + i < out_cap) dst[before + i] = src[i];
+}
+
 #define WB_CASC_CONFIGS(X) X(8, 4) X(4, 4) X(2, 4) X(1, 4) X(8, 8) X(4, 8) X(2, 8) X(1, 8) X(2, 16) X(1, 16)
 
 template <int D>
@@ -809,15 +868,20 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
     WB_REQUIRE(det || shard_capacity == 0, "wb_cascade_launch: det is null but capacity > 0");
     WB_REQUIRE(batch >= 1 && batch <= 65535, "wb_cascade_launch: batch %d out of range", batch);
     WB_REQUIRE(n_levels >= 1 && n_tiles >= 1, "wb_cascade_launch: empty launch");
-    WB_REQUIRE(chn_dtype == WB_DTYPE_F32 || chn_dtype == WB_DTYPE_U8, "wb_cascade_launch: channel dtype %d (float32 or uint8)", chn_dtype);
+    WB_REQUIRE(chn_dtype == WB_DTYPE_F32 || chn_dtype == WB_DTYPE_U8 || chn_dtype == WB_DTYPE_RANK8,
+               "wb_cascade_launch: channel dtype %d (float32, uint8 or ranks)", chn_dtype);
     CascArgs a;
     a.chn = chn;
-    a.chn_u8 = chn_dtype == WB_DTYPE_U8;
+    a.chn_u8 = chn_dtype != WB_DTYPE_F32;
     a.chn_stride = chn_stride;
     a.levels = levels;
     a.tiles = tiles;
     a.n_levels = n_levels;
-    a.stages = a.chn_u8 ? model->stages_u8_dev : model->stages_dev;
+    // WB_DTYPE_RANK8: the bytes are threshold ranks of this model (wb_channels_launch wrote them): the uint8 tile
+    // kernel with the rank records
+    const bool ranks = chn_dtype == WB_DTYPE_RANK8;
+    WB_REQUIRE(!ranks || (model->bin_ok && !model->generic), "wb_cascade_launch: this model has no rank tables (wb_model_info: rank_ok)");
+    a.stages = ranks ? model->stages_bin_dev : (a.chn_u8 ? model->stages_u8_dev : model->stages_dev);
     a.T = model->n_stages;
     a.m = model->m;
     a.n = model->n;
@@ -842,6 +906,8 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
         return s;
     }();
     for (int i = 0; i < 4; ++i) a.spar[i] = spar.v[i];
+    static const int spar_wg = getenv("WB_CASC_SPAR_WG") ? atoi(getenv("WB_CASC_SPAR_WG")) : 128;
+    a.spar_wg = spar_wg;
     dim3 grid((unsigned)n_tiles, (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;
     if (model->generic) {
@@ -945,6 +1011,17 @@ extern "C" int wb_tree_apply_launch(void *stream, const void *X, int x_dtype, in
     WB_REQUIRE(blocks <= 0x7fffffff, "wb_tree_apply_launch: too many samples for one launch");
     hipLaunchKernelGGL(tree_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X,
                        (int)(x_dtype == WB_DTYPE_U8), n_samples, m, n, C, feature, threshold, left, right, n_nodes, node);
+    WB_HIP_CHECK(hipGetLastError());
+    return WB_OK;
+}
+
+extern "C" int wb_det_pack_launch(void *stream, const WbDet *det, const uint32_t *det_count, uint32_t shard_capacity,
+                                  int32_t *packed, uint32_t packed_capacity) {
+    WB_REQUIRE(det_count && packed, "wb_det_pack_launch: null pointer");
+    WB_REQUIRE(det || shard_capacity == 0, "wb_det_pack_launch: det is null but capacity > 0");
+    WB_REQUIRE(reinterpret_cast<uintptr_t>(packed) % 16 == 0, "wb_det_pack_launch: packed must be 16-byte aligned");
+    hipLaunchKernelGGL(det_pack_kernel, dim3(WB_DET_SHARDS), dim3(256), 0, (hipStream_t)stream, det, det_count,
+                       shard_capacity, packed, packed_capacity);
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;
 }

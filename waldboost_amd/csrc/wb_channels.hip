@@ -35,6 +35,12 @@ struct ChanArgs {
     double tri[11];      // grad_mag: triangle_kernel(5) (float32 values, widened)
     float gm_eps;        // grad_mag: float32(1e-3)
     int dbg;             // diagnostics (WB_CHAN_DBG): 1 = stop after step 1, 2 = after step 2, 4 = skip the stores
+    // optional second output of channels_kernel: the pixels as threshold ranks of one model (WB_DTYPE_RANK8)
+    uint8_t *rank;       // [u][v][4] bytes per level, same element offsets as chn; nullptr = none
+    int64_t rank_stride;
+    const uint4 *rank_lut;   // WbModel::bin_lut_dev: float S[4][256], then uint8 base[4][WB_BIN_CELLS]
+    int rank_iters;
+    float rank_k[4], rank_b[4];
 };
 
 // Diagnostic build only (make STAMPS=1): thread 0 of every workgroup stores s_memrealtime at the
@@ -450,7 +456,8 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
     constexpr int HS = G::HS, SU = G::SU, SV = G::SV, RH = G::RH, RW = G::RW, P = G::P;
     constexpr int PATCH_BYTES = sizeof(T) == 1 ? G::PATCH_BYTES : 0;
     constexpr int UNI_BYTES = G::SH_BYTES > PATCH_BYTES ? G::SH_BYTES : PATCH_BYTES;
-    __shared__ float R[RH * RW];
+    constexpr int R_FLOATS = RH * RW > WB_BIN_LUT_BYTES / 4 ? RH * RW : WB_BIN_LUT_BYTES / 4;   // (R later holds the rank tables)
+    __shared__ __attribute__((aligned(16))) float R[R_FLOATS];
     __shared__ __attribute__((aligned(16))) unsigned char uni[UNI_BYTES];
     __shared__ uint32_t odd_values;      // set when a shrunk value lies outside the exact-sum range (see step 3)
     F4 *Sh = reinterpret_cast<F4 *>(uni);
@@ -559,7 +566,25 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
         }
         Sh[p] = F4{o[0], o[1], o[2], o[3]};
     }
+    // rank tables of the model (12 KiB, L2-resident): requested before the barrier, parked in R -- dead once every
+    // thread has left step 2 -- right behind it
+    constexpr int LUT_PER_THREAD = WB_BIN_LUT_BYTES / 16 / 256;
+    static_assert(WB_BIN_LUT_BYTES % (16 * 256) == 0, "whole 16-byte vectors per thread");
+    const bool ranks = a.rank != nullptr;
+    static_assert(LUT_PER_THREAD == 3, "three vectors per thread below");
+    uint4 lut0 = make_uint4(0, 0, 0, 0), lut1 = lut0, lut2 = lut0;
+    if (ranks) {
+        lut0 = a.rank_lut[tid];
+        lut1 = a.rank_lut[tid + 256];
+        lut2 = a.rank_lut[tid + 512];
+    }
     __syncthreads();
+    if (ranks) {
+        uint4 *lut = reinterpret_cast<uint4 *>(R);
+        lut[tid] = lut0;
+        lut[tid + 256] = lut1;
+        lut[tid + 512] = lut2;
+    }
     WB_CSTAMP(5);
 
     if (a.dbg & 2) return;
@@ -620,8 +645,31 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
         if (su >= L.u || sv >= L.v || (a.dbg & 4)) continue;
         if (SMOOTH && (su == 0 || sv == 0 || su == L.u - 1 || sv == L.v - 1)) o[y][0] = o[y][1] = o[y][2] = o[y][3] = 0.0f;
         // one float4 per pixel ([u][v][4]): 64 lanes store 1 KiB contiguous
-        float4 *dst = reinterpret_cast<float4 *>(out + ((int64_t)su * L.v + sv) * 4);
-        *dst = make_float4(o[y][0], o[y][1], o[y][2], o[y][3]);
+        if (a.chn) {
+            float4 *dst = reinterpret_cast<float4 *>(out + ((int64_t)su * L.v + sv) * 4);
+            *dst = make_float4(o[y][0], o[y][1], o[y][2], o[y][3]);
+        }
+    }
+    if (ranks) {
+        // the same pixels as threshold ranks, one dword per pixel (wb_common.h: wb_bin_rank)
+        __syncthreads();                                      // the tables are in R
+        const float *Sthr = reinterpret_cast<const float *>(R);
+        const uint8_t *base = reinterpret_cast<const uint8_t *>(R) + 4 * WB_BIN_SLOTS * 4;
+        uint32_t *rout = reinterpret_cast<uint32_t *>(a.rank + (int64_t)b * a.rank_stride + L.chn_off);
+        const int K = a.rank_iters;
+#pragma unroll
+        for (int y = 0; y < RPT; ++y) {
+            const int su = u0 + i0 + y;
+            if (su >= L.u || sv >= L.v || (a.dbg & 4)) continue;
+            uint32_t w = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t r = wb_bin_rank(o[y][k], a.rank_k[k], a.rank_b[k], base + k * WB_BIN_CELLS, Sthr + k * WB_BIN_SLOTS, K);
+                if constexpr (sizeof(T) != 1) r = o[y][k] != o[y][k] ? 255u : r;      // a NaN pixel fails every `v <= thr`
+                w |= r << (8 * k);
+            }
+            rout[(int64_t)su * L.v + sv] = w;
+        }
     }
     WB_CSTAMP(7);
 }
@@ -1055,8 +1103,13 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
                                   int64_t oct_stride, int dtype, int batch, const WbLevel *levels,
                                   int n_levels, const WbTile *tiles, int n_tiles, const uint32_t *minmax,
                                   int n_oct, const WbTap *taps, int channel_func, int shrink, int smooth,
-                                  const double *cs_sn, void *chn, int64_t chn_stride) {
-    WB_REQUIRE(img && levels && tiles && minmax && taps && chn, "wb_channels_launch: null pointer");
+                                  const double *cs_sn, void *chn, int64_t chn_stride, const WbModel *rank_model,
+                                  uint8_t *rank, int64_t rank_stride) {
+    WB_REQUIRE(img && levels && tiles && minmax && taps && (chn || rank), "wb_channels_launch: null pointer");
+    WB_REQUIRE(!rank == !rank_model, "wb_channels_launch: rank and rank_model go together");
+    WB_REQUIRE(!rank || channel_func == WB_CHN_GRAD_HIST, "wb_channels_launch: ranks are written for grad_hist channels only");
+    WB_REQUIRE(!rank || rank_model->bin_ok, "wb_channels_launch: this model has no rank tables (wb_model_info: rank_ok)");
+    WB_REQUIRE(!rank || reinterpret_cast<uintptr_t>(rank) % 4 == 0, "wb_channels_launch: rank must be 4-byte aligned");
     WB_REQUIRE(cs_sn || channel_func != WB_CHN_GRAD_HIST, "wb_channels_launch: grad_hist needs the orientation constants");
     WB_REQUIRE(batch >= 1 && n_levels >= 1 && n_tiles >= 1, "wb_channels_launch: empty launch");
     WB_REQUIRE(batch <= 65535, "wb_channels_launch: batch %d exceeds grid.y limit", batch);
@@ -1074,6 +1127,18 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
     a.n_oct = n_oct;
     a.chn = chn;
     a.chn_stride = chn_stride;
+    a.rank = rank;
+    a.rank_stride = rank_stride;
+    a.rank_lut = nullptr;
+    a.rank_iters = 0;
+    if (rank) {
+        a.rank_lut = reinterpret_cast<const uint4 *>(rank_model->bin_lut_dev);
+        a.rank_iters = rank_model->bin_iters;
+        for (int k = 0; k < 4; ++k) {
+            a.rank_k[k] = rank_model->bin_k[k];
+            a.rank_b[k] = rank_model->bin_b[k];
+        }
+    }
     if (cs_sn) set_constants(a, cs_sn);
     static const int dbg = getenv("WB_CHAN_DBG") ? atoi(getenv("WB_CHAN_DBG")) : 0;
     a.dbg = dbg;

@@ -47,6 +47,10 @@ __host__ __device__ inline float wb_key_f32(uint32_t k) {
 // ---- cascade geometry ----
 #define WB_CASC_TC 64        // windows per tile row = one per lane
 #define WB_CASC_MAX_DEPTH 3
+#define WB_BIN_MAX 255       // distinct thresholds per channel a binned tile can rank in one byte (255 = NaN pixel)
+#define WB_BIN_SLOTS 256     // entries of a channel's sorted threshold table
+#define WB_BIN_CELLS 2048    // cells of a channel's lookup grid
+#define WB_BIN_LUT_BYTES (4 * WB_BIN_SLOTS * 4 + 4 * WB_BIN_CELLS)   // float S[4][256], then uint8 base[4][N]
 
 // The canonical stage record the cascade kernels read with scalar loads:
 //   int   off[NI]   LDS byte offset of each internal node's feature (BFS order)
@@ -71,6 +75,17 @@ struct WbModel {
     int32_t *stages_dev;        // (n_stages + G) stage records with LDS byte offsets (planar float32 tile)
     int32_t *stages_u8_dev;     // the same for uint8 channels: offsets into the interleaved byte tile, integer thresholds
     int lds_bytes_u8;           // dynamic LDS of the kernel on uint8 channels
+    // float32 channels as threshold RANKS (written by the channel kernel, scanned by the uint8 cascade tile): per
+    // channel the model's distinct thresholds are sorted, a pixel is replaced by the number of them below it (its
+    // rank, one byte), and a node test `v <= thr` becomes `rank(v) <= index(thr)` -- the same decision for every
+    // float, in a quarter of the bytes
+    int bin_ok;                 // 1 = every channel has <= WB_BIN_MAX distinct thresholds and the tables fit
+    int bin_cells;              // N: cells of the linear lookup grid per channel
+    int bin_iters;              // K: most thresholds that share one cell (refinement steps per pixel)
+    float bin_k[4], bin_b[4];   // cell(v) = trunc(clamp(fma(v, k[c], b[c]), 0, N - 1))
+    int bin_lut_vec;            // size of the table block in 16-byte units
+    uint8_t *bin_lut_dev;       // float S[4][256] (sorted thresholds, +inf padded), then uint8 base[4][N]
+    int32_t *stages_bin_dev;    // stage records for the binned tile: byte-tile offsets, thresholds = ranks
     // trees deeper than WB_CASC_MAX_DEPTH: generic node-walk kernel on the reference's own flat arrays
     int generic;                // 1 = use cascade_generic_kernel
     int32_t *g_node_off;        // [n_stages + 1]
@@ -80,3 +95,18 @@ struct WbModel {
     float *g_pred;              // [n_nodes]
     float *g_theta;             // [n_stages]
 };
+
+// ---- threshold ranks of float32 channel values (WbModel::bin_*, WB_DTYPE_RANK8) ----
+// cell of a channel's lookup grid (host mirror: bin_cell() in wb_api.hip): non-decreasing in v
+__device__ inline uint32_t wb_bin_cell(float v, float k, float b) {
+    const float q = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, k, b), 0.0f, (float)(WB_BIN_CELLS - 1));
+    return (uint32_t)q;
+}
+// rank of v among the channel's sorted distinct thresholds S (+inf padded): the number of them below v.
+// base[cell] counts the thresholds of lower cells (all below v); the thresholds of v's own cell follow in S, in
+// order, at most K of them; thresholds of higher cells are above v.  (NaN: the caller substitutes 255.)
+__device__ inline uint32_t wb_bin_rank(float v, float k, float b, const uint8_t *base, const float *S, int K) {
+    uint32_t r = base[wb_bin_cell(v, k, b)];
+    for (int i = 0; i < K; ++i) r += v > S[r] ? 1u : 0u;
+    return r;
+}

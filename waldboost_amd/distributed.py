@@ -1,11 +1,18 @@
 """Multi-GPU sharding of image batches and the gather of detections.
 
 The path shards embarrassingly (images are independent): one process per GPU,
-each scans a contiguous chunk of the batch with its own resident cascade; the only exchange is
-one gather of the fixed-size detection records at the end (RCCL over xGMI with backend "nccl";
-"gloo" in the CPU tests).  The payload is tiny (16 B per detection), so this is a single
-latency-bound collective of a fixed-size prefix of each rank's detection buffer -- no ring, no
-bucketing.
+each scans its own contiguous chunk of the batch with its own resident cascade; no collective on
+the data path.  The exchange at the end is small and latency-bound (16 B per detection):
+
+  * one all-gather of three integers per rank (largest shard fill, valid records, images) -- every
+    rank learns whether ANY rank overflowed its detection buffer, and all of them then grow to the
+    same capacity and scan again together (a rank never re-allocates on its own);
+  * one gather of the valid record prefixes, padded to the longest, to the destination rank;
+  * one all-reduce (sum) of the per-level alive[level, stage] counters -- the reference's additive
+    n_loc / n_weak statistics (model.py:248,252).
+
+RCCL over xGMI with backend "nccl"; "gloo" in the CPU tests.  `DetectionGatherer` is the sync-free
+variant bench.py overlaps with the next step: a fixed-size all-gather with no host read-back.
 """
 import numpy as np
 
@@ -66,43 +73,133 @@ class DetectionGatherer:
         return out[order]
 
 
-def detect_sharded(model, images, group=None):
-    """Detect on a batch that is split over the ranks of `group` (one process per GPU): every rank
-    passes the SAME global batch [B,H,W] (host array) and scans its contiguous shard; the detection
-    records of all ranks are then gathered with one collective.  Returns, on every rank, the merged
-    records (numpy structured array of WbDet with GLOBAL image indices, reference order) and the
-    per-image alive counts of the local shard."""
+# ------------------------------------------------------------------------------ the end-of-batch exchange
+def _comm_device(group=None):
+    """Where collective payloads live: the GPU for RCCL ("nccl"), the host for gloo."""
+    import torch
     import torch.distributed as dist
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def agree_capacity(scan, group=None):
+    """Bring every rank's detection buffer to a capacity no rank overflows.  `scan` is the rank's scan state:
+    ``scan.cap`` (records per shard), ``scan.need()`` (largest shard fill of the last scan; may exceed cap)
+    and ``scan.grow(cap)`` (re-allocate to `cap` records per shard and scan again).  All ranks take the same
+    decisions: the MAX over ranks of need and of cap is what every rank compares and grows to, so buffer sizes
+    never diverge -- also when a single rank overflowed.  Returns the number of rounds (0 = nobody overflowed)."""
+    import torch
+    import torch.distributed as dist
+    dev = _comm_device(group)
+    rounds = 0
+    while True:
+        t = torch.tensor([int(scan.need()), int(scan.cap), -int(scan.cap)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        need, cap_max, cap_min = int(t[0]), int(t[1]), -int(t[2])
+        if need <= cap_min and cap_min == cap_max:            # the same three numbers on every rank: same decision
+            return rounds
+        target = cap_max if need <= cap_max else int(need * 1.5) + 16
+        if scan.cap != target or scan.need() > scan.cap:
+            scan.grow(target)
+        rounds += 1
+
+
+def gather_records(recs, n_images, group=None, dst=0, first_image=None):
+    """Gather every rank's valid detection records (int32 [n, 4] = WbDet rows with LOCAL image indices) to rank
+    `dst`: an all-gather of (n, n_images) per rank, then one gather of the prefixes padded to the longest.
+    Image indices become global: rank r's image i -> first_image[r] + i, by default the ranks' contiguous shards
+    in rank order.  Returns on `dst` the merged WbDet array in reference order (image, level, r, c); on the
+    other ranks None."""
+    import torch
+    import torch.distributed as dist
+    from ._native import DET_DTYPE
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = _comm_device(group)
+    recs = torch.as_tensor(recs, dtype=torch.int32).reshape(-1, 4)
+    meta = torch.zeros((world, 2), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(meta, torch.tensor([[recs.shape[0], int(n_images)]], dtype=torch.int64, device=dev), group=group)
+    meta = meta.cpu().numpy()
+    n_max = int(meta[:, 0].max())
+    send = torch.zeros((max(n_max, 1), 4), dtype=torch.int32, device=dev)
+    send[: recs.shape[0]] = recs.to(dev)
+    dst_global = dist.get_global_rank(group, dst) if group is not None else dst
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bufs, dst=dst_global, group=group)
+    if rank != dst:
+        return None
+    if first_image is None:
+        first_image = np.concatenate([[0], np.cumsum(meta[:-1, 1])])
+    parts = []
+    for r in range(world):
+        d = bufs[r][: int(meta[r, 0])].cpu().numpy().copy().view(DET_DTYPE).reshape(-1)
+        d["image"] += int(first_image[r])
+        parts.append(d)
+    out = np.concatenate(parts)
+    return out[np.lexsort((out["c"], out["r"], out["level"], out["image"]))]
+
+
+def reduce_alive(alive_levels, group=None):
+    """Sum of alive[level, stage] over the ranks (int64), on every rank."""
+    import torch
+    import torch.distributed as dist
+    t = torch.as_tensor(np.ascontiguousarray(alive_levels, np.int64)).to(_comm_device(group))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()
+
+
+class _EngineScan:
+    """agree_capacity's view of a PyramidEngine + cascade."""
+
+    def __init__(self, eng, dm):
+        self.eng, self.dm = eng, dm
+        self.stt = eng.run(dm)
+
+    @property
+    def cap(self):
+        return self.eng.detb.cap
+
+    def need(self):
+        return self.eng.detb.max_count()
+
+    def grow(self, cap):
+        from . import _native as nat
+        self.eng.det_capacity = int(cap) * nat.WB_DET_SHARDS
+        self.eng._alloc_det()
+        self.stt = self.eng.run_cascade(self.dm, ranks=self.stt.get("ranks", False))
+
+
+def detect_sharded(model, images, group=None, dst=0):
+    """Detect on a batch that is split over the ranks of `group` (one process per GPU).  `images` is THIS rank's
+    shard [b, H, W] (host array or device tensor; b may differ between ranks, the shards are consecutive in rank
+    order -- `shard_range` cuts a global batch that way).  Every rank scans its shard with no data-path
+    collective; then the exchange described in the module docstring.  Returns
+
+        det    on rank `dst`: all detections as a WbDet array with GLOBAL image indices in reference order
+               (image, level, r, c); None on the other ranks
+        alive  [b, levels, stages] of the local shard
+        total  [levels, stages] summed over all ranks (every rank)
+
+    and adds the GLOBAL n_loc / n_weak to the model's counters on every rank (reference model.py:248,252 are
+    plain sums over the images scanned)."""
     from . import engine as _engine
     from . import channels as _channels
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    B = int(images.shape[0])
-    lo, hi = shard_range(B, rank, world)
-    counts = [shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world)]
-    nb = max(counts)                                   # every rank runs the same (padded) batch size
+    b = int(images.shape[0])
     shrink, n_per_oct, smooth, spec = _channels.read_opts(model.channel_opts)
     H, W = int(images.shape[1]), int(images.shape[2])
-    eng = _engine.get_engine(H, W, images.dtype, shrink, n_per_oct, smooth, nb, channels=spec)
-    local = np.zeros((nb, H, W), images.dtype)
-    local[: hi - lo] = images[lo:hi]
+    dtype = images.dtype if isinstance(images, np.ndarray) else {"torch.uint8": np.uint8, "torch.float32": np.float32}[str(images.dtype)]
     dm = model.device_cascade()
-    eng.load_images(local)
-    stt = eng.run(dm)
-    eng.ensure_capacity(dm)
-    g = DetectionGatherer(eng.detb, group)
-    g.gather(eng.detb)
-    merged = g.merged([nb] * world)                    # image index = rank * nb + local index
-    # drop the padding images and renumber to the global batch
-    keep = np.zeros(merged.size, bool)
-    glob = np.zeros(merged.size, np.int32)
-    for r in range(world):
-        rlo = shard_range(B, r, world)[0]
-        sel = (merged["image"] >= r * nb) & (merged["image"] < r * nb + counts[r])
-        keep |= sel
-        glob[sel] = merged["image"][sel] - r * nb + rlo
-    out = merged[keep].copy()
-    out["image"] = glob[keep]
-    order = np.lexsort((out["c"], out["r"], out["level"], out["image"]))
     T = len(model)
-    alive = stt["alive"][: hi - lo, :, :T].cpu().numpy().astype(np.int64)
-    return out[order], alive
+    eng = _engine.get_engine(H, W, dtype, shrink, n_per_oct, smooth, max(b, 1), channels=spec)
+    if b:
+        eng.load_images(images)
+    scan = _EngineScan(eng, dm)                       # (a rank with an empty shard scans one blank image and drops it)
+    agree_capacity(scan, group)
+    L = eng.plan.n_levels
+    alive = scan.stt["alive"][:b, :, :T].cpu().numpy().astype(np.int64).reshape(b, L, T)
+    counts = eng.shard_counts(dm)
+    recs = eng.detb.valid_records(counts).cpu() if b else np.zeros((0, 4), np.int32)
+    det = gather_records(recs, b, group, dst)
+    tot = reduce_alive(np.concatenate([alive.sum(axis=0).reshape(-1), [b]]), group)
+    total, n_images = tot[:-1].reshape(L, T), int(tot[-1])
+    model.n_loc += n_images * eng.plan.n_loc(dm.m, dm.n)
+    model.n_weak += int(total.sum())
+    return det, alive, total

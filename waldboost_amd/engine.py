@@ -9,6 +9,7 @@ torch is used only for device memory, streams and graph capture; all compute is 
 csrc/*.hip.  Nothing here falls back to the CPU.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -17,6 +18,7 @@ from .chanfunc import SPECS
 from .plan import PyramidPlan, N_CHANNELS
 
 _TORCH_DT = {}
+_NO_RANKS = bool(os.environ.get("WB_NO_RANKS"))     # diagnostic: float32 channels + planar float tile everywhere
 
 
 def _torch_dtype(np_dtype):
@@ -86,6 +88,9 @@ class DeviceCascade:
         self.n_stages, self.depth = info.n_stages, info.depth
         self.m, self.n, self.C = info.m, info.n, info.C
         self.tile_rows, self.tile_cols, self.lds_bytes = info.tile_rows, info.tile_cols, info.lds_bytes
+        # the model's thresholds fit rank tables: the channel kernel can write float32 channels as one-byte ranks
+        # (WB_DTYPE_RANK8) and the cascade scan them exactly as it would the floats, from a quarter of the bytes
+        self.rank_ok = bool(info.rank_ok)
 
     def __del__(self):
         try:
@@ -145,6 +150,8 @@ def sort_records(d):
 
 
 class PyramidEngine:
+    _FETCH_ROWS = 4096            # detection records read back with the first copy of fetch()
+
     def __init__(self, H, W, dtype, shrink, n_per_oct, smooth, batch=1, exact_single=False, det_capacity=1 << 16,
                  channels=None):
         import torch
@@ -183,7 +190,9 @@ class PyramidEngine:
         self.chn = self._chn_flat[: self.batch * self.chn_stride].view(self.batch, self.chn_stride)
         self.cs_sn = orientation_constants()
         self._oct_off = (C.c_int64 * max(p.n_oct, 1))(*[int(x) for x in p.oct_off[:max(p.n_oct, 1)]])
+        self.rank = self._rank_flat = self.rank_owner = None
         self.det_capacity = int(det_capacity)
+        self._h_packed = self._h_alive = self._fetch_ev = None
         self._alloc_det()
         self.alive = None
         self._casc = {}
@@ -204,21 +213,29 @@ class PyramidEngine:
         self.det_capacity = cap * nat.WB_DET_SHARDS
         self.detb = DetBuffer(cap, self.dev)
         self.det_buf = self.detb.buf
+        self.packed = None            # header + all valid records back to back (wb_det_pack_launch), allocated on first use
 
     # ------------------------------------------------------------------ input
     def load_images(self, images):
         """images: ndarray / tensor [B,H,W] (or [H,W]) of the engine's dtype."""
         import torch
+        want = (self.batch, self.plan.H, self.plan.W)
         if isinstance(images, np.ndarray):
             if images.dtype != self.dtype:
                 raise TypeError(f"engine built for {self.dtype} images, got {images.dtype}")
-            t = torch.from_numpy(np.ascontiguousarray(images))
+            if images.ndim == 2:
+                images = images[None]
+            if tuple(images.shape) != want:
+                raise ValueError(f"expected images of shape {want}, got {tuple(images.shape)}")
+            t = None
         else:
-            t = images
-        if t.dim() == 2:
-            t = t[None]
-        if tuple(t.shape) != (self.batch, self.plan.H, self.plan.W):
-            raise ValueError(f"expected images of shape {(self.batch, self.plan.H, self.plan.W)}, got {tuple(t.shape)}")
+            t = images[None] if images.dim() == 2 else images
+            if tuple(t.shape) != want:
+                raise ValueError(f"expected images of shape {want}, got {tuple(t.shape)}")
+        if t is None:
+            # (a page-locked staging buffer was measured: memcpy + DMA came out 10 % slower per Model.detect call
+            # than torch's own pipelined upload from pageable memory)
+            t = torch.from_numpy(np.ascontiguousarray(images))
         self.img.copy_(t, non_blocking=True)
 
     # ------------------------------------------------------------------ launches
@@ -230,21 +247,36 @@ class PyramidEngine:
                                              p.H * p.W, nat.ptr(self.oct), p.oct_total, self._oct_off, p.n_oct,
                                              nat.ptr(self.minmax)), "wb_octaves_launch")
 
-    def launch_channels(self):
+    def ranks_for(self, dm):
+        """True when the fused detection path applies: grad_hist channels written straight as threshold ranks of
+        cascade `dm` (float32 channels never reach HBM)."""
+        return dm is not None and dm.rank_ok and self.spec.key == "grad_hist" and not _NO_RANKS
+
+    def launch_channels(self, rank_dm=None, floats=True):
+        """The channel pyramid of every resident image.  rank_dm: also (floats=False: only) write the channels as
+        WB_DTYPE_RANK8 bytes for that cascade into self.rank."""
+        import torch
         p = self.plan
         if p.n_levels == 0:
             return
+        if rank_dm is not None and self.rank is None:
+            self._rank_flat = torch.zeros(self.batch * self.chn_stride + 16, dtype=torch.uint8, device=self.dev)
+            self.rank = self._rank_flat[: self.batch * self.chn_stride].view(self.batch, self.chn_stride)
         nat.check(self.lib.wb_channels_launch(nat.stream_ptr(), nat.ptr(self.img), p.H * p.W, nat.ptr(self.oct),
                                               p.oct_total, self.wb_dtype, self.batch, nat.ptr(self.levels),
                                               p.n_levels, nat.ptr(self.chan_tiles), self.n_chan_tiles,
                                               nat.ptr(self.minmax), max(p.n_oct, 1), nat.ptr(self.taps),
                                               self.spec.func_id, p.shrink, p.smooth,
-                                              self.cs_sn.ctypes.data_as(C.POINTER(C.c_double)), nat.ptr(self.chn),
-                                              self.chn_stride), "wb_channels_launch")
+                                              self.cs_sn.ctypes.data_as(C.POINTER(C.c_double)),
+                                              nat.ptr(self.chn if floats or rank_dm is None else None), self.chn_stride,
+                                              rank_dm.handle if rank_dm is not None else None,
+                                              nat.ptr(self.rank if rank_dm is not None else None), self.chn_stride),
+                  "wb_channels_launch")
+        self.rank_owner = rank_dm               # whose ranks self.rank holds (None: stale)
 
-    def run_channels(self):
+    def run_channels(self, rank_dm=None, floats=True):
         self.launch_octaves()
-        self.launch_channels()
+        self.launch_channels(rank_dm, floats)
 
     def _casc_state(self, dm):
         import torch
@@ -263,13 +295,17 @@ class PyramidEngine:
             self._casc = {key: stt}          # one cascade resident per engine
         return stt
 
-    def launch_cascade(self, dm, reduce=True):
+    def launch_cascade(self, dm, reduce=True, ranks=False):
         """The cascade scan; reduce=False launches the tile kernel alone (no per-level statistics), which
-        is what bench.py times for the roofline of that kernel."""
+        is what bench.py times for the roofline of that kernel.  ranks=True scans self.rank (written for `dm` by
+        launch_channels) instead of the channel buffer."""
         stt = self._casc_state(dm)
         if stt["n_tiles"] == 0:
             return stt
-        nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.chn), self.spec.wb_dtype,
+        if ranks and self.rank_owner is not dm:
+            raise RuntimeError("the rank buffer does not hold this cascade's ranks (launch_channels(rank_dm=...) first)")
+        nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.rank if ranks else self.chn),
+                                             nat.WB_DTYPE_RANK8 if ranks else self.spec.wb_dtype,
                                              self.chn_stride,
                                              self.batch, nat.ptr(self.levels), self.plan.n_levels,
                                              nat.ptr(stt["tiles"]), nat.ptr(stt["csr"]), stt["n_tiles"],
@@ -278,17 +314,21 @@ class PyramidEngine:
                   "wb_cascade_launch")
         return stt
 
-    def run_cascade(self, dm):
+    def run_cascade(self, dm, ranks=False):
         """Zero the counters and scan every level of every image with cascade `dm`."""
         stt = self._casc_state(dm)
         self.detb.zero()
         if stt["n_tiles"] == 0:
             stt["alive"].zero_()
-        return self.launch_cascade(dm)
+        stt["ranks"] = ranks                       # (a re-scan after a buffer overflow repeats the same form)
+        return self.launch_cascade(dm, ranks=ranks)
 
     def run(self, dm):
-        self.run_channels()
-        return self.run_cascade(dm)
+        """octaves -> channels -> cascade for one model: the detection path (reference model.py:149-179).  When
+        the cascade has rank tables the channels go to HBM as ranks only."""
+        fused = self.ranks_for(dm)
+        self.run_channels(dm if fused else None, floats=not fused)
+        return self.run_cascade(dm, ranks=fused)
 
     # ------------------------------------------------------------------ hipGraph
     def capture(self, dm):
@@ -317,7 +357,7 @@ class PyramidEngine:
                 return int(self.detb.counts.sum().item())
             self.det_capacity = (int(need * 1.5) + 16) * nat.WB_DET_SHARDS
             self._alloc_det()
-            self.run_cascade(dm)
+            self.run_cascade(dm, ranks=self._casc_state(dm).get("ranks", False))
 
     def shard_counts(self, dm):
         """Host copy of the shard counters after the last scan; re-runs the cascade with a larger buffer if a
@@ -328,7 +368,43 @@ class PyramidEngine:
                 return counts
             self.det_capacity = (int(counts.max() * 1.5) + 16) * nat.WB_DET_SHARDS
             self._alloc_det()
-            self.run_cascade(dm)
+            self.run_cascade(dm, ranks=self._casc_state(dm).get("ranks", False))
+
+    def fetch(self, dm, stt):
+        """Everything the host needs from the last scan in ONE synchronisation: the shard contents packed on
+        the device (wb_det_pack_launch), then asynchronous copies of the header + first records and of
+        alive[B, L, T] into page-locked memory, one event wait.  Grows the buffer and scans again if a shard
+        overflowed; a second copy only when there are more than _FETCH_ROWS detections.
+        Returns (records int32 [n, 4] in shard order, alive int64 [B, L, T])."""
+        import torch
+        T = dm.n_stages
+        while True:
+            if self.packed is None:
+                self.packed = torch.empty((1 + self.detb.NS * self.detb.cap, 4), dtype=torch.int32, device=self.dev)
+            if self._h_packed is None:
+                self._h_packed = torch.empty((1 + self._FETCH_ROWS, 4), dtype=torch.int32).pin_memory()
+                self._fetch_ev = torch.cuda.Event()
+            if self._h_alive is None or self._h_alive.shape != stt["alive"].shape:
+                self._h_alive = torch.empty(stt["alive"].shape, dtype=torch.int32).pin_memory()
+            nat.check(self.lib.wb_det_pack_launch(nat.stream_ptr(), nat.ptr(self.detb.recs), nat.ptr(self.detb.counts),
+                                                  self.detb.cap, nat.ptr(self.packed), self.packed.shape[0] - 1),
+                      "wb_det_pack_launch")
+            rows = min(self._h_packed.shape[0], self.packed.shape[0])
+            self._h_packed[:rows].copy_(self.packed[:rows], non_blocking=True)
+            self._h_alive.copy_(stt["alive"], non_blocking=True)
+            self._fetch_ev.record()
+            self._fetch_ev.synchronize()
+            total, worst = int(self._h_packed[0, 0]), int(self._h_packed[0, 1])
+            if worst <= self.detb.cap:
+                break
+            self.det_capacity = (int(worst * 1.5) + 16) * nat.WB_DET_SHARDS
+            self._alloc_det()
+            stt = self.run_cascade(dm, ranks=stt.get("ranks", False))
+        recs = self._h_packed[1:1 + min(total, rows - 1)].numpy().copy()
+        if total > rows - 1:
+            recs = np.concatenate([recs, self.packed[rows:1 + total].cpu().numpy()])
+        alive = self._h_alive.numpy()[:, :, :T].astype(np.int64)
+        return recs, alive
 
     def sorted_detections(self, n=None):
         """Detections ordered by (image, level, r, c) as an int32 [n, 4] tensor of WbDet records."""
@@ -346,12 +422,25 @@ class PyramidEngine:
                                                nat.ptr(boxes), nat.ptr(scores)), "wb_boxes_launch")
         return boxes, scores
 
+    def inv_scales(self):
+        """float32(1.0 / scale) per level: the factor get_boxes multiplies with (reference model.py:147)."""
+        if getattr(self, "_inv_scales", None) is None:
+            self._inv_scales = np.array([np.float32(1.0 / s) for s in self.plan.scales], np.float32)
+        return self._inv_scales
+
     def level_tensor(self, b, l):
         """Channels of level l of image b as a device view [u,v,C] into the pyramid buffer."""
         lv = self.plan.levels[l]
         off = int(self.level_np[l]["chn_off"])
         u, v, C = lv["u"], lv["v"], self.spec.n_channels
         return self.chn[b, off:off + u * v * C].view(u, v, C)
+
+    def read_rank_level(self, b, l):
+        """Ranks of level l of image b as a uint8 ndarray [u,v,4] (after launch_channels(rank_dm=...))."""
+        lv = self.plan.levels[l]
+        off = int(self.level_np[l]["chn_off"])
+        u, v = lv["u"], lv["v"]
+        return self.rank[b, off:off + u * v * 4].reshape(u, v, 4).cpu().numpy()
 
     def read_level(self, b, l):
         """Channels of level l of image b as a fresh HWC ndarray [u,v,C] of the channel function's dtype."""

@@ -76,13 +76,19 @@ class Model:
 
     def device_cascade(self):
         """The device-side cascade for the current stage list.  `classifier` and `theta` are plain
-        public lists in the reference and callers edit them in place, so the cached handle is
-        keyed by their current content, not only by `append` calls."""
-        # (theta by repr: the float kind matters to theta_as_f32; one join over all tree arrays: 65 us for 128 stages)
-        sig = (tuple(self.shape), tuple(map(repr, self.theta)),
-               b"".join([a.tobytes() for w in self.classifier for a in (w.feature, w.threshold, w.left, w.right, w.prediction)]))
+        public lists in the reference and callers edit them in place, so the cached handle is keyed
+        by the lists' current content: the identity of every tree and the value and kind of every
+        theta.  A tree's arrays are frozen (made read-only) once they have been uploaded, so a later
+        in-place edit of an array raises instead of leaving a stale copy on the GPU; replace the
+        DTree to change a stage."""
+        # (theta by repr: the float kind matters to theta_as_f32, and NaN compares unequal to itself)
+        sig = (tuple(self.shape), tuple(map(id, self.classifier)), tuple(map(repr, self.theta)))
         if self._device is None or self._device[0] != sig:
-            self._device = (sig, _engine.DeviceCascade(self.shape, self.classifier, self.theta))
+            dev = _engine.DeviceCascade(self.shape, self.classifier, self.theta)
+            for w in self.classifier:
+                for a in (w.feature, w.threshold, w.left, w.right, w.prediction):
+                    a.setflags(write=False)
+            self._device = (sig, dev, list(self.classifier))     # (the list keeps the ids alive and unique)
         return self._device[1]
 
     # ---- pyramid (reference model.py:95-134)
@@ -155,34 +161,39 @@ class Model:
                         r=np.empty(0, np.int64), c=np.empty(0, np.int64), alive=np.zeros((0, T), np.int64),
                         scales=[])
         eng.load_images(image)
-        eng.run_channels()
-        return self.scan_engine(eng)
+        fused = eng.ranks_for(dm)                        # channels straight to threshold ranks of this cascade
+        eng.run_channels(dm if fused else None, floats=not fused)
+        return self.scan_engine(eng, ranks=fused, dm=dm)
 
-    def scan_engine(self, eng):
+    def scan_engine(self, eng, ranks=False, dm=None):
         """Run this cascade over the channel pyramid already resident in `eng` (channels computed
         by the caller: several models can share one pyramid, reference __init__.py:120-124).
         Returns the same dict as detect_raw and updates n_loc / n_weak."""
         m, n, Cc = self.shape
         assert Cc == eng.spec.n_channels, f"Invalid number of channels. Expected {Cc} given {eng.spec.n_channels}."
-        dm = self.device_cascade()
+        dm = dm if dm is not None else self.device_cascade()
         T = len(self)
-        stt = eng.run_cascade(dm)
-        counts = eng.shard_counts(dm)                     # one small D2H copy (re-runs the scan if a shard overflowed)
-        n_det = int(counts.sum())
-        alive = stt["alive"][0, :, :T].cpu().numpy().astype(np.int64).reshape(eng.plan.n_levels, T)
+        stt = eng.run_cascade(dm, ranks=ranks)
+        recs, alive = eng.fetch(dm, stt)                  # ONE host synchronisation: packed records + statistics
+        alive = alive[0].reshape(eng.plan.n_levels, T)
+        n_det = recs.shape[0]
         self.n_loc += eng.plan.n_loc(m, n)
         self.n_weak += int(alive.sum())
         if n_det <= _HOST_POST_MAX:
-            # few detections (the usual case): one copy of the valid records, then order and boxes on the
-            # host -- the same float32 arithmetic as boxes_kernel, without three launches and four copies
-            d = eng.detb.valid_records(counts).cpu().numpy().view(nat.DET_DTYPE).reshape(-1)
-            d = d[np.lexsort((d["c"], d["r"], d["level"]))]
-            inv = np.array([np.float32(1.0 / sc) for sc in eng.plan.scales], np.float32)[d["level"]] if n_det else np.zeros(0, "f")
-            x1, y1 = d["c"].astype(np.float32), d["r"].astype(np.float32)
-            x2, y2 = (d["c"].astype(np.int32) + n).astype(np.float32), (d["r"].astype(np.int32) + m).astype(np.float32)
-            boxes = np.stack([x1 * inv, y1 * inv, x2 * inv, y2 * inv], 1) if n_det else np.empty((0, 4), "f")
-            return dict(boxes=boxes, scores=d["score"].copy(), level=d["level"].copy(), r=d["r"].astype(np.int64),
-                        c=d["c"].astype(np.int64), alive=alive, scales=list(eng.plan.scales))
+            # few detections (the usual case): order and boxes on the host -- the same float32 arithmetic as
+            # boxes_kernel, without three launches and four copies
+            d = recs.view(nat.DET_DTYPE).reshape(-1)
+            level, r, c = d["level"].astype(np.int64), d["r"].astype(np.int64), d["c"].astype(np.int64)
+            order = np.argsort((level << 32) | (r << 16) | c)        # (level, r, c): unique keys, any sort kind
+            level, r, c, score = level[order], r[order], c[order], d["score"][order]
+            inv = eng.inv_scales()[level] if n_det else np.zeros(0, "f")
+            boxes = np.empty((n_det, 4), np.float32)
+            np.multiply(c.astype(np.float32), inv, out=boxes[:, 0])
+            np.multiply(r.astype(np.float32), inv, out=boxes[:, 1])
+            np.multiply((c + n).astype(np.float32), inv, out=boxes[:, 2])
+            np.multiply((r + m).astype(np.float32), inv, out=boxes[:, 3])
+            return dict(boxes=boxes, scores=score, level=level.astype(np.int32), r=r, c=c, alive=alive,
+                        scales=list(eng.plan.scales))
         det = eng.sorted_detections()
         boxes, scores = eng.boxes(det, dm)
         d = det.cpu().numpy().view(nat.DET_DTYPE).reshape(-1)

@@ -53,7 +53,7 @@ class DTree:
         key = str(dev)
         cache = self.__dict__.setdefault("_dev", {})
         if key not in cache:
-            cache[key] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in
+            cache[key] = tuple(torch.from_numpy(np.array(a)).to(dev) for a in
                                (self.feature, self.threshold, self.left, self.right, self.prediction))
         return cache[key]
 
