@@ -272,3 +272,17 @@ def test_sample_pool_bookkeeping_without_a_gpu():
     assert X.shape == (1, 2, 2, 1) and H.tolist() == [2.0]
     X[...] = -1                                                  # copies: the pool is not touched
     assert pool.get_samples(SampleLabel.FALSE_POSITIVE)[0].min() >= 0
+
+
+def test_get_regression_target_follows_the_reference():
+    """reference samples.py:152-157: dt - gt[instance_id], and the error when boxes are unlabelled."""
+    from waldboost_amd.boxes import Boxes
+    from waldboost_amd.samples import get_regression_target
+    dt = Boxes(np.array([[10, 10, 30, 30], [50, 52, 70, 75], [0, 0, 5, 5]], np.float32))
+    gt = Boxes(np.array([[12, 9, 33, 31], [48, 50, 72, 74]], np.float32))
+    with pytest.raises(ValueError):
+        get_regression_target(dt, gt)
+    dt.set_field("instance_id", np.array([0, 1, -1], np.int32))      # -1 indexes the last box, as NumPy does upstream
+    get_regression_target(dt, gt)
+    want = dt.get() - gt.get()[[0, 1, -1]]
+    assert np.array_equal(dt.get_field("regression_target"), want)

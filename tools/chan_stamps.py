@@ -12,15 +12,19 @@ lib.wb_debug_channel_stamps.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTE
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 e = PyramidEngine(1080, 1920, np.uint8, 2, 8, 1, batch=B)
 e.load_images(np.stack([synth_image(1080, 1920, s) for s in range(B)]))
-e.run_channels(); torch.cuda.synchronize()
+import waldboost_amd as wb
+M = wb.load(os.path.join(ROOT, "tests/golden/models/cfg2_d2_T128.pb"))
+dm = M.device_cascade()
+RANKS = len(sys.argv) > 2 and sys.argv[2] == "ranks"          # the fused detection form: ranks only
+e.run_channels(dm if RANKS else None, floats=not RANKS); torch.cuda.synchronize()
 for _ in range(3):
-    e.launch_channels()
+    e.launch_channels(dm if RANKS else None, floats=not RANKS)
 torch.cuda.synchronize()
 n_wg = min(e.n_chan_tiles * B, 1 << 17)
 out = (C.c_double * 7)(); life = C.c_double()
 lib.wb_debug_channel_stamps(n_wg, out, C.byref(life))
 names = ["tile/level/extent loads", "stage source patch + barrier", "row loop (resample)", "leftover columns + barrier",
-         "step 2 (gradients, projection, shrink) + barrier", "step 3 (smooth)", "stores"]
-print(f"B={B}: {n_wg} workgroups, mean lifetime {life.value:.2f} us")
+         "step 2 (gradients, projection, shrink) + barrier", "step 3 (smooth)", "stores (+ ranks)"]
+print(f"{'ranks' if RANKS else 'float32 channels'} B={B}: {n_wg} workgroups, mean lifetime {life.value:.2f} us")
 for n, v in zip(names, out):
     print(f"  {n:50s} {v:6.2f} us")

@@ -23,6 +23,10 @@ class Boxes:
             raise ValueError(f"field {name!r} has {value.shape[0]} rows, boxes have {len(self)}")
         self._fields[name] = value
 
+    def add_field(self, name, value):
+        """As set_field (bbx exposes both; reference samples.py:157 adds 'regression_target' with it)."""
+        self.set_field(name, value)
+
     def get_field(self, name):
         return self._fields[name]
 

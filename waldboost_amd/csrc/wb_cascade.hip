@@ -160,6 +160,7 @@ template <int D, int RPW, int WAVES, bool U8>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) void cascade_tile_kernel(CascArgs a, const int32_t *__restrict__ stages) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t wcnt[WAVES];
+    __shared__ uint32_t wcnt2[WAVES];    // the count exchange at stage 16 (its own words: a wave may already be writing wcnt for the epilogue)
     __shared__ uint32_t wg_base;
     constexpr int NT = WAVES * 64;
     constexpr int TR = RPW * WAVES;
@@ -449,7 +450,36 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
 
     static_assert(S0 == 8, "the pooling above assumes phase A ends at stage 8");
     if (a.dbg & 8) return;
-    if (!scatter) run_segments(T);
+    if (!scatter) {
+        // After the segment [8, 16) the tile usually holds a few dozen windows in a few sparse chunks, with ~100
+        // stages to go: count them workgroup-wide once more and, if they are few, deal them out to all waves for
+        // the stage-parallel evaluator (as above after phase A).
+        constexpr int S1 = 2 * S0;
+        if (RPW >= 2 && pooled && T > S1) {
+            run_segments(S1);
+            if (lane == 0) wcnt2[wave] = (uint32_t)n_q;
+            __syncthreads();
+            uint32_t total2 = 0, before2 = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const uint32_t c = wcnt2[w];
+                if (w < wave) before2 += c;
+                total2 += c;
+            }
+            const uint32_t room = 64u * WAVES * (RPW - 1);             // queue entries behind the pooled chunks
+            if (total2 <= ((uint32_t)a.spar_wg < room ? (uint32_t)a.spar_wg : room)) {   // same decision in every wave
+                uint2 *list2 = wgq + 64 * WAVES;                      // (the pooled chunks occupy the first 64 * WAVES entries)
+                for (int i = lane; i < n_q; i += 64) list2[before2 + i] = queue[i];
+                __syncthreads();
+                scatter = true;
+                queue = list2 + wave;
+                qs = WAVES;
+                n_q = (int)total2 > wave ? ((int)total2 - wave + WAVES - 1) / WAVES : 0;
+                t_begin = S1;
+            }
+        }
+        if (!scatter) run_segments(T);
+    }
     WB_STAMP(4);
     if (a.dbg & 16) return;
 

@@ -62,6 +62,14 @@ __device__ unsigned long long g_chan_stamps[WB_CSTAMP_WGS * WB_CSTAMP_SLOTS];
 
 typedef WbTap Tap;   // one axis of the bilinear resample (scipy NI_ZoomShift, order 1), host-built table
 
+// a double held by lane `k` (wave-uniform k), to every lane
+__device__ inline double lane_f64(double v, int k) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, k);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), k);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // scipy's order-1 resample of one output pixel: fp64, taps and additions in NI_ZoomShift's order
 __device__ inline double resample_f64(double v00, double v01, double v10, double v11, const Tap &tr, const Tap &tc) {
     double t = (v00 * tr.w0) * tc.w0;
@@ -84,6 +92,10 @@ template <> struct Src<uint8_t> {
     static __device__ bool fast(float v00, float v01, float v10, float v11, float wr0, float wr1, float wc0, float wc1,
                                 float &out) {
         float top = __builtin_fmaf(v01, wc1, v00 * wc0), bot = __builtin_fmaf(v11, wc1, v10 * wc0);
+        return fast_rows(top, bot, wr0, wr1, out);
+    }
+    // the same from the two rows' horizontal interpolations (a row's value is shared by the output rows that tap it)
+    static __device__ bool fast_rows(float top, float bot, float wr0, float wr1, float &out) {
         float t = __builtin_fmaf(bot, wr1, top * wr0);
         float fl = floorf(t), fr = t - fl;
         out = fl;
@@ -95,13 +107,14 @@ template <> struct Src<uint8_t> {
         t = fmin(fmax(t, mn), mx);
         return (float)(int)t;
     }
-    // [1,2,1] pass: exact in fp32 for integer pixels (|.| <= 1020)
-    static __device__ float hpass(float a, float b, float c) { return b * 2.0f + (a + c); }
+    // [1,2,1] pass: exact in fp32 for integer pixels (|.| <= 1020); 2b is exact, so the fma rounds like b*2 + (a+c)
+    static __device__ float hpass(float a, float b, float c) { return __builtin_fmaf(b, 2.0f, a + c); }
     static __device__ float dpass(float lo, float hi) { return lo - hi; }
 };
 template <> struct Src<float> {
     static constexpr bool kFastResample = false;
     static __device__ bool fast(float, float, float, float, float, float, float, float, float &) { return false; }
+    static __device__ bool fast_rows(float, float, float, float, float &) { return false; }
     static __device__ double lo(uint32_t k) { return (double)wb_key_f32(k); }
     // float32 images: zoom stores fp32, then np.clip in fp32
     static __device__ float finish(double t, double mn, double mx) {
@@ -301,42 +314,89 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             const Tap trl = rtap[ly];
             const int l_o0 = (trl.i0 - r_lo) * PPITCH;
             const float l_wr0 = (float)trl.w0, l_wr1 = (float)trl.w1;
-            // RB rows per pass: every tap byte of the pass is requested before the first is used, and
-            // the rare exact redo is deferred behind all the fast-path arithmetic (one branch per pass)
-            constexpr int RB = 2;
-            for (int k0 = wave; k0 < RH; k0 += 4 * RB) {
+            // Each wave owns a strip of consecutive tile rows and walks it two rows per pass: every tap byte of
+            // the pass is requested before the first is used, and the rare exact redo is deferred behind all the
+            // fast-path arithmetic (one branch per pass).  Consecutive output rows of a down-scale by less than 2
+            // usually share a source row (the lower taps of row k are the upper taps of row k + 1): its
+            // horizontal interpolation -- two conversions, a multiply and an fma per pixel -- is then taken
+            // over instead of recomputed; which rows share is wave-uniform (the row taps are scalars).
+#ifndef WB_CHAN_RB
+#define WB_CHAN_RB 2
+#endif
+            constexpr int RB = WB_CHAN_RB;
+            constexpr int RS = (RH + 3) / 4;
+            const int k_lo = wave * RS, k_hi = k_lo + RS < RH ? k_lo + RS : RH;
+            float hprev[NCS];                     // horizontal interpolation of the patch row at byte offset o_prev,
+            uint8_t pb[NCS][2];                   // and its two tap bytes (the exact redo wants them)
+            int o_prev = -1;
+#pragma unroll
+            for (int c = 0; c < NCS; ++c) {
+                hprev[c] = 0.0f;
+                pb[c][0] = pb[c][1] = 0;
+            }
+            auto hlerp = [&](uint8_t x0, uint8_t x1, int c) { return __builtin_fmaf((float)x1, wc1f[c], (float)x0 * wc0f[c]); };
+            for (int k0 = k_lo; k0 < k_hi; k0 += RB) {
                 uint8_t b[RB][NCS][4];
                 float wr0[RB], wr1[RB];
+                int o0[RB];
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
-                    int k = k0 + 4 * rb;
-                    k = k < RH ? k : RH - 1;
-                    const int o0 = __builtin_amdgcn_readlane(l_o0, k);
+                    int k = k0 + rb;
+                    k = k < k_hi ? k : k_hi - 1;
+                    o0[rb] = __builtin_amdgcn_readlane(l_o0, k);
                     wr0[rb] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l_wr0), k));
                     wr1[rb] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l_wr1), k));
+                    // (a00, a01) / (a10, a11) sit at i0, i0 + 1 of two consecutive patch rows; the upper pair is
+                    // not read again when it is the previous row's lower pair
+                    const int o_above = rb == 0 ? o_prev : o0[rb - 1] + PPITCH;
+                    if (o0[rb] != o_above) {                                    // wave-uniform
+#pragma unroll
+                        for (int c = 0; c < NCS; ++c) {
+                            const unsigned char *q = patch + o0[rb] + ci0[c];
+                            b[rb][c][0] = q[0]; b[rb][c][1] = q[1];
+                        }
+                    }
 #pragma unroll
                     for (int c = 0; c < NCS; ++c) {
-                        // (a00, a01) / (a10, a11) sit at i0, i0 + 1 of two consecutive patch rows
-                        const unsigned char *q = patch + o0 + ci0[c];
-                        b[rb][c][0] = q[0]; b[rb][c][1] = q[1]; b[rb][c][2] = q[PPITCH]; b[rb][c][3] = q[PPITCH + 1];
+                        const unsigned char *q = patch + o0[rb] + ci0[c];
+                        b[rb][c][2] = q[PPITCH]; b[rb][c][3] = q[PPITCH + 1];
                     }
                 }
                 float out[RB][NCS];
                 bool redo = false;
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
+                for (int rb = 0; rb < RB; ++rb) {
+                    float top[NCS], bot[NCS];
+                    if (o0[rb] == o_prev) {                                     // wave-uniform
 #pragma unroll
-                    for (int c = 0; c < NCS; ++c)
-                        redo |= !Src<T>::fast((float)b[rb][c][0], (float)b[rb][c][1], (float)b[rb][c][2], (float)b[rb][c][3],
-                                              wr0[rb], wr1[rb], wc0f[c], wc1f[c], out[rb][c]);
+                        for (int c = 0; c < NCS; ++c) {
+                            top[c] = hprev[c];
+                            b[rb][c][0] = pb[c][0]; b[rb][c][1] = pb[c][1];
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < NCS; ++c) top[c] = hlerp(b[rb][c][0], b[rb][c][1], c);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NCS; ++c) {
+                        bot[c] = hlerp(b[rb][c][2], b[rb][c][3], c);
+                        hprev[c] = bot[c];
+                        pb[c][0] = b[rb][c][2]; pb[c][1] = b[rb][c][3];
+                        redo |= !Src<T>::fast_rows(top[c], bot[c], wr0[rb], wr1[rb], out[rb][c]);
+                    }
+                    o_prev = o0[rb] + PPITCH;
+                }
                 if (redo) {                                                // rare: exact fp64 with the full taps
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) {
-                        int k = k0 + 4 * rb;
-                        k = k < RH ? k : RH - 1;
-                        int y = ry0 + k;
-                        y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
-                        const Tap tr = rtap[y];
+                        int k = k0 + rb;
+                        k = k < k_hi ? k : k_hi - 1;
+                        // the row's fp64 weights come from the lane that holds them (no memory access: a load
+                        // from the tap table here stalled the whole pass behind an L2 round trip)
+                        Tap tr;
+                        tr.i0 = tr.i1 = 0;
+                        tr.w0 = lane_f64(trl.w0, k);
+                        tr.w1 = lane_f64(trl.w1, k);
 #pragma unroll
                         for (int c = 0; c < NCS; ++c) {
                             float f;
@@ -349,8 +409,8 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                 }
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
-                    const int k = k0 + 4 * rb;
-                    if (k < RH) {
+                    const int k = k0 + rb;
+                    if (k < k_hi) {
 #pragma unroll
                         for (int c = 0; c < NCS; ++c) R[k * RW + lane + 64 * c] = out[rb][c];
                     }
@@ -657,6 +717,19 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
         const uint8_t *base = reinterpret_cast<const uint8_t *>(R) + 4 * WB_BIN_SLOTS * 4;
         uint32_t *rout = reinterpret_cast<uint32_t *>(a.rank + (int64_t)b * a.rank_stride + L.chn_off);
         const int K = a.rank_iters;
+        // all RPT x 4 values of the thread advance together: every step is RPT * 4 independent LDS lookups (one
+        // value at a time, the 1 + K dependent lookups of each value were a chain of LDS latencies)
+        uint32_t r[RPT][4];
+#pragma unroll
+        for (int y = 0; y < RPT; ++y)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[y][k] = base[k * WB_BIN_CELLS + wb_bin_cell(o[y][k], a.rank_k[k], a.rank_b[k])];
+        for (int i = 0; i < K; ++i) {
+#pragma unroll
+            for (int y = 0; y < RPT; ++y)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r[y][k] += o[y][k] > Sthr[k * WB_BIN_SLOTS + r[y][k]] ? 1u : 0u;
+        }
 #pragma unroll
         for (int y = 0; y < RPT; ++y) {
             const int su = u0 + i0 + y;
@@ -664,9 +737,9 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
             uint32_t w = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                uint32_t r = wb_bin_rank(o[y][k], a.rank_k[k], a.rank_b[k], base + k * WB_BIN_CELLS, Sthr + k * WB_BIN_SLOTS, K);
-                if constexpr (sizeof(T) != 1) r = o[y][k] != o[y][k] ? 255u : r;      // a NaN pixel fails every `v <= thr`
-                w |= r << (8 * k);
+                uint32_t rk = r[y][k];
+                if constexpr (sizeof(T) != 1) rk = o[y][k] != o[y][k] ? 255u : rk;      // a NaN pixel fails every `v <= thr`
+                w |= rk << (8 * k);
             }
             rout[(int64_t)su * L.v + sv] = w;
         }
@@ -833,10 +906,13 @@ __global__ void selftest_projection_kernel(ChanArgs a, uint32_t *mismatches) {
 
 template <typename T, int S, int TU, int TV, bool FAST>
 void launch_variant(hipStream_t st, dim3 grid, const ChanArgs &a, bool smooth) {
+    // diagnostic (WB_CHAN_XLDS=bytes): extra dynamic LDS per workgroup lowers the workgroups per CU, to tell a
+    // latency-bound kernel (time ~ 1 / residency) from a throughput-bound one (time unchanged)
+    static const size_t xlds = getenv("WB_CHAN_XLDS") ? (size_t)atoi(getenv("WB_CHAN_XLDS")) : 0;
     if (smooth)
-        hipLaunchKernelGGL((channels_kernel<T, S, TU, TV, true, FAST>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((channels_kernel<T, S, TU, TV, true, FAST>), grid, dim3(256), xlds, st, a);
     else
-        hipLaunchKernelGGL((channels_kernel<T, S, TU, TV, false, FAST>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((channels_kernel<T, S, TU, TV, false, FAST>), grid, dim3(256), xlds, st, a);
 }
 
 template <typename T, bool FAST>

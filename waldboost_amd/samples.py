@@ -109,6 +109,15 @@ def label_boxes(dt_boxes, gt_boxes, min_tp_iou: float = 0.7, max_fp_iou: float =
     dt_boxes.set_field("tp_label", labels)
 
 
+def get_regression_target(dt_boxes, gt_boxes):
+    """Box offsets of labelled detections to the ground truth they belong to, as field
+    'regression_target' (reference samples.py:152-157; host arithmetic on a handful of boxes)."""
+    if not dt_boxes.has_field("instance_id"):
+        raise ValueError("'instance_id' field is missing")
+    owner = dt_boxes.get_field("instance_id")
+    dt_boxes.add_field("regression_target", dt_boxes.get() - gt_boxes[owner].get())
+
+
 # --------------------------------------------------------------------------------------- mining
 def get_samples_from_image(model, image, gt_boxes, tp=True, fp=True, **kwargs):
     """Generator over the pyramid levels that hold selected detections of `model` on `image`: Boxes
