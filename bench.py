@@ -72,23 +72,27 @@ N_SIMD, CLOCK_GHZ = 256 * 4, 2.4          # MI355X_MICROARCH.md: 256 CUs x 4 SIM
 
 def issue_bound(roof, batch, channels):
     """The bound that actually binds these kernels: vector-instruction issue.  From the committed SQ counters
-    (rocprofv3 --pmc passes, profiles/r02/sq_counters.json: instructions per launch per image), a wave64 VALU
-    instruction occupies its SIMD's issue port for at least 2 cycles (4 for conversions, fp64, transcendental),
-    so `floor_us` = VALU instructions x 2 cycles / (1024 SIMDs x 2.4 GHz) is the time the dominant kernel's
-    instruction stream needs if nothing ever stalls; `frac` = floor / measured duration."""
+    (three rocprofv3 --pmc passes, profiles/r02/sq_counters.json, instructions per image), a wave64 VALU
+    instruction holds its SIMD's issue port for 2 cycles at best (MI355X_MICROARCH.md: v_fma_f32 2 cycles) and
+    for 4 when it is a conversion or an fp64 operation (tools/valu_rate_probe.hip), so
+        floor_us = (VALU + CVT + F64) instructions x 2 cycles / (1024 SIMDs x 2.4 GHz)
+    is the time the dominant kernel's instruction stream needs if no wave ever waits; frac = floor / measured."""
     path = os.path.join(PROFILE_DIR, "sq_counters.json")
-    if roof is None or not os.path.exists(path):
+    if roof is None or channels != "grad_hist" or not os.path.exists(path):
         return None
     with open(path) as f:
-        cj = json.load(f)
-    k = cj.get(channels, {}).get(roof["kernel"])
+        k = json.load(f).get(roof["kernel"])
     if not k:
         return None
-    valu, salu = k["SQ_INSTS_VALU_per_image"] * batch, k["SQ_INSTS_SALU_per_image"] * batch
-    floor_us = valu * 2.0 / (N_SIMD * CLOCK_GHZ * 1e3)
-    return {"kernel": roof["kernel"], "bound": "valu_issue", "valu_insts_per_launch": valu, "salu_insts_per_launch": salu,
-            "floor_us": floor_us, "measured_us": roof["avg_launch_ms"] * 1e3, "frac": floor_us / (roof["avg_launch_ms"] * 1e3),
-            "counters": "profiles/r02/sq_counters.json", "note": "wave64 VALU = 2 issue cycles minimum; 1024 SIMDs at 2.4 GHz"}
+    g = lambda name: k.get(name + "_per_image", 0.0) * batch
+    valu, salu = g("SQ_INSTS_VALU"), g("SQ_INSTS_SALU")
+    slow = g("SQ_INSTS_VALU_CVT") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_FMA_F64")
+    floor_us = (valu + slow) * 2.0 / (N_SIMD * CLOCK_GHZ * 1e3)
+    return {"kernel": roof["kernel"], "bound": "valu_issue", "valu_insts_per_launch": valu, "of_which_4_cycle": slow,
+            "salu_insts_per_launch": salu, "floor_us": floor_us, "measured_us": roof["avg_launch_ms"] * 1e3,
+            "frac": floor_us / (roof["avg_launch_ms"] * 1e3), "counters": "profiles/r02/sq_counters.json",
+            "note": "2 issue cycles per wave64 VALU instruction, 4 for conversions and fp64; 1024 SIMDs at 2.4 GHz"}
+
 
 def event_time_ms(fn, iters, torch):
     """Average duration of fn() over `iters` back-to-back launches, HIP events on the launch stream."""

@@ -77,6 +77,30 @@ def test_channel_pyramid_vs_oracle(shape, dtype):
         assert np.array_equal(bits(c), bits(rc))
 
 
+def test_channel_pyramid_is_lazy_and_survives_interleaving():
+    """reference channels.py:125-146: a level is computed when the generator is advanced to it.  Two generators
+    over different images of one shape share the cached engine and still yield their own levels; a consumer that
+    stops early leaves the later levels uncomputed."""
+    from waldboost_amd import engine as _engine
+    opts = dict(wb.default_channel_opts)
+    oo = dict(opts)
+    oo["channels"] = orc.CHANNEL_FUNCS["grad_hist"]
+    a, b = synth_image(150, 200, 71), synth_image(150, 200, 72)
+    ra, rb = list(orc.channel_pyramid(a, oo)), list(orc.channel_pyramid(b, oo))
+    ga, gb = wb.channels.channel_pyramid(a, opts), wb.channels.channel_pyramid(b, opts)
+    for l in range(len(ra)):
+        (ca, sa), (cb, sb) = next(ga), next(gb)
+        assert sa == ra[l][1] and np.array_equal(bits(ca), bits(ra[l][0]))
+        assert sb == rb[l][1] and np.array_equal(bits(cb), bits(rb[l][0]))
+    eng = _engine.get_engine(150, 200, np.uint8, 2, 8, 1, 1)
+    eng.chn.fill_(float("nan"))
+    g = wb.channels.channel_pyramid(a, opts)
+    next(g), next(g)
+    g.close()
+    assert not np.isnan(eng.read_level(0, 1)).any()
+    assert np.isnan(eng.read_level(0, 2)).all() and np.isnan(eng.read_level(0, len(ra) - 1)).all()
+
+
 def test_clean_edges_hit_the_projection_leftovers():
     """Noise-free blocks, ramps and 45-degree edges: gy == 0 / gx == +-gy over whole 2x2 blocks, so the
     1e-13..1e-16-sized leftovers of the fp64 projection survive the shrink and reach the smooth
@@ -281,6 +305,47 @@ def test_predict_on_image_and_tree_eval_vs_oracle():
     for w, t in zip(M.classifier[:4], trees[:4]):
         got = w.predict_on_image(X, prs, pcs)
         assert np.array_equal(bits(got), bits(orc.tree_predict_on_image(t, X, prs, pcs)))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float16, np.int16, np.int32, np.int64, np.uint16, np.uint32, np.bool_])
+def test_channel_arrays_of_any_dtype_compare_as_numpy_does(dtype):
+    """reference training.py:92 / model.py:199 compare X with the float32 thresholds in whatever arithmetic NumPy
+    promotes to (float64 for float64 / int32 / int64 arrays): the values handed to the kernels must decide every
+    node the same way (waldboost_amd/compare.py).  Thresholds are placed on and next to the array's values."""
+    rng = np.random.default_rng(17)
+    if dtype == np.float64:
+        X = rng.uniform(0, 60, (40, 90, 4))
+        X[::3] = np.float32(X[::3]) + 1e-9                       # just above a float32 value
+    elif dtype == np.float16:
+        X = rng.uniform(0, 60, (40, 90, 4)).astype(dtype)
+    elif dtype == np.bool_:
+        X = rng.integers(0, 2, (40, 90, 4)).astype(dtype)
+    else:
+        hi = min(np.iinfo(dtype).max, 2 ** 26)
+        X = rng.integers(hi - 70, hi, (40, 90, 4)).astype(dtype)     # int32/int64: beyond float32's integers
+    vals = np.unique(X.astype(np.float64))
+    M = wb.Model((12, 12, 4), dict(wb.default_channel_opts))
+    acc = 0.0
+    for t in range(12):
+        f, th, l, r, p = random_tree_arrays(rng, (12, 12, 4), 2, 0.0, 1.0)
+        pick = np.float32(rng.choice(vals, th.size))
+        th = np.where(rng.random(th.size) < 0.5, pick, np.nextafter(pick, np.float32(np.inf))).astype(np.float32)
+        acc -= 0.3
+        M.append(wb.DTree(f, th, l, r, p), float(np.float32(acc)))
+    shape, _, trees, thetas = oracle_model(M)
+    rs, cs, hs, alive = M.predict_on_image_stats(X)
+    ors, ocs, ohs, oalive = orc.cascade_predict_on_image(shape, trees, thetas, X)
+    assert np.array_equal(alive, oalive) and ohs.size > 0
+    assert np.array_equal(rs, ors) and np.array_equal(cs, ocs) and np.array_equal(bits(hs), bits(ohs))
+    prs, pcs = rng.integers(0, 28, 500), rng.integers(0, 78, 500)
+    for w, t in zip(M.classifier[:3], trees[:3]):
+        assert np.array_equal(bits(w.predict_on_image(X, prs, pcs)), bits(orc.tree_predict_on_image(t, X, prs, pcs)))
+    crops = np.stack([X[r:r + 12, c:c + 12] for r, c in zip(prs[:50], pcs[:50])])
+    H, mask = M.predict(crops)
+    oH, omask = orc.model_predict(shape, trees, thetas, crops)
+    assert np.array_equal(mask, omask) and np.array_equal(bits(H), bits(oH))
+    with pytest.raises(TypeError):
+        M.predict_on_image(X.astype(np.complex64))
 
 
 def test_theta_scalar_kinds_follow_numpy_promotion():

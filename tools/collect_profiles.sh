@@ -1,20 +1,32 @@
 #!/bin/bash
-# Collect the round's bench lines and rocprofv3 summaries on the GPU box (run via gpurun from the
-# repo root; results land in gpurun_out/prof/ and are copied into profiles/ by hand).
+# Collect the round's bench lines and rocprofv3 summaries on the GPU box (run via gpurun from the repo root):
+#   tools/collect_profiles.sh gpurun_out/prof    -> copy the summaries you want judged into profiles/rNN/ by hand.
+# Counter passes use --kernel-trace + --pmc only (no other trace domains).
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-O=gpurun_out/prof
+O=${1:-gpurun_out/prof}
 rm -rf $O && mkdir -p $O
-timeout -k 10 400 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
+timeout -k 10 500 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -5 $O/bench_default.err; exit 1; }
 echo "default bench done"
 timeout -k 10 300 python3 bench.py --batch 64 --steps 10 --warmup 2 --pool 2 --streams 2 --no-cpu-baseline > $O/bench_batch64.json 2>> $O/bench_default.err || exit 1
-timeout -k 10 300 python3 bench.py --channels grad_hist_4_u1 --no-cpu-baseline > $O/bench_gh4u1.json 2>> $O/bench_default.err || exit 1
+timeout -k 10 300 python3 bench.py --channels grad_hist_4_u1 --no-cpu-baseline > $O/bench_grad_hist_4_u1.json 2>> $O/bench_default.err || exit 1
+timeout -k 10 300 python3 bench.py --channels grad_hist_4_u1 --batch 64 --steps 10 --warmup 2 --pool 2 --streams 2 --no-cpu-baseline > $O/bench_grad_hist_4_u1_batch64.json 2>> $O/bench_default.err || exit 1
+WB_NO_RANKS=1 timeout -k 10 300 python3 bench.py --batch 64 --steps 10 --warmup 2 --pool 2 --streams 2 --no-cpu-baseline > $O/bench_batch64_float_channels.json 2>> $O/bench_default.err || exit 1
 echo "bench lines done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_default --output-format csv -- python3 bench.py --no-cpu-baseline > $O/stats_default.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_streams1 --output-format csv -- python3 bench.py --no-cpu-baseline --streams 1 > $O/stats_streams1.log 2>&1 || exit 1
+S="--no-cpu-baseline --no-through-api --repeats 2"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_default --output-format csv -- python3 bench.py $S > $O/stats_default.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_streams1 --output-format csv -- python3 bench.py $S --streams 1 > $O/stats_streams1.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_batch64 --output-format csv -- python3 bench.py $S --batch 64 --steps 10 --warmup 2 --pool 2 --streams 1 > $O/stats_batch64.log 2>&1 || exit 1
 echo "kernel stats done"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch --output-format csv -- python3 bench.py --no-cpu-baseline --steps 8 --warmup 2 --no-graph --streams 1 > $O/pmc_fetch.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write --output-format csv -- python3 bench.py --no-cpu-baseline --steps 8 --warmup 2 --no-graph --streams 1 > $O/pmc_write.log 2>&1 || exit 1
+T="--no-cpu-baseline --no-through-api --repeats 1 --steps 8 --warmup 2 --no-graph --streams 1"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch --output-format csv -- python3 bench.py $T > $O/pmc_fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write --output-format csv -- python3 bench.py $T > $O/pmc_write.log 2>&1 || exit 1
 echo "traffic passes done"
-find $O -name "*.csv" | head -30
+python3 tools/traffic_summary.py $O/pmc_fetch $O/pmc_write > $O/traffic_pmc.json
+for d in stats_default stats_streams1 stats_batch64; do
+  f=$(find $O/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv
+done
+rm -rf $O/stats_default $O/stats_streams1 $O/stats_batch64 $O/pmc_fetch $O/pmc_write
+tools/collect_sq.sh $O/sq > /dev/null 2>&1 && cp $O/sq/sq_counters.txt $O/sq/sq_counters.json $O/ && rm -rf $O/sq
+ls -la $O

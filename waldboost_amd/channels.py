@@ -125,10 +125,11 @@ def read_opts(channel_opts):
 
 
 def channel_pyramid(image, channel_opts):
-    """Generate the channel pyramid of `image` (lazy generator, like the reference).
-
-    The whole pyramid is computed on the GPU in one launch group when the first level is
-    requested; levels are copied to the host one by one as they are consumed."""
+    """Generate the channel pyramid of `image` -- a lazy generator, like the reference (channels.py:125-146):
+    the octaves are built when the first level is requested, and each level's channels are computed on the GPU
+    (one launch over that level's tiles) and copied to the host only when the generator is advanced to it, so a
+    caller that stops early pays for the levels it consumed.  (Model.detect does not go through this generator:
+    it computes the whole pyramid in one launch and scans it on the GPU.)"""
     _validate_image(image)
     shrink, n_per_oct, smooth, spec = read_opts(channel_opts)
     if spec.dtype == np.uint8:
@@ -137,7 +138,13 @@ def channel_pyramid(image, channel_opts):
     eng = _engine.get_engine(H, W, image.dtype, shrink, n_per_oct, smooth, 1, channels=spec)
     if eng.plan.n_levels == 0:
         return
-    eng.load_images(image)
-    eng.run_channels()
+    mine = None
     for l in range(eng.plan.n_levels):
+        if eng.epoch != mine:
+            # first level -- or the (cached, shared) engine has served another image since the last one was
+            # yielded: bring this generator's image and octaves back
+            eng.load_images(image)
+            eng.launch_octaves()
+            mine = eng.epoch
+        eng.launch_level(l)
         yield np.atleast_3d(eng.read_level(0, l)), eng.plan.scales[l]

@@ -936,7 +936,7 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
         return s;
     }();
     for (int i = 0; i < 4; ++i) a.spar[i] = spar.v[i];
-    static const int spar_wg = getenv("WB_CASC_SPAR_WG") ? atoi(getenv("WB_CASC_SPAR_WG")) : 128;
+    static const int spar_wg = getenv("WB_CASC_SPAR_WG") ? atoi(getenv("WB_CASC_SPAR_WG")) : 64;
     a.spar_wg = spar_wg;
     dim3 grid((unsigned)n_tiles, (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;

@@ -191,6 +191,8 @@ class PyramidEngine:
         self.cs_sn = orientation_constants()
         self._oct_off = (C.c_int64 * max(p.n_oct, 1))(*[int(x) for x in p.oct_off[:max(p.n_oct, 1)]])
         self.rank = self._rank_flat = self.rank_owner = None
+        self._level_tiles = None
+        self.epoch = 0
         self.det_capacity = int(det_capacity)
         self._h_packed = self._h_alive = self._fetch_ev = None
         self._alloc_det()
@@ -219,6 +221,7 @@ class PyramidEngine:
     def load_images(self, images):
         """images: ndarray / tensor [B,H,W] (or [H,W]) of the engine's dtype."""
         import torch
+        self.epoch += 1                       # (lazy consumers notice that the resident images changed)
         want = (self.batch, self.plan.H, self.plan.W)
         if isinstance(images, np.ndarray):
             if images.dtype != self.dtype:
@@ -273,6 +276,30 @@ class PyramidEngine:
                                               nat.ptr(self.rank if rank_dm is not None else None), self.chn_stride),
                   "wb_channels_launch")
         self.rank_owner = rank_dm               # whose ranks self.rank holds (None: stale)
+
+    def launch_level(self, l):
+        """The float/uint8 channels of ONE level of every resident image (after launch_octaves): what a lazy
+        consumer of the pyramid asks for, level by level (reference channels.py:125-146 computes a level only
+        when the generator is advanced to it)."""
+        import torch
+        p = self.plan
+        if self._level_tiles is None:
+            tiles = p.chan_tiles()
+            self._level_tiles = []
+            for k in range(p.n_levels):
+                sel = np.ascontiguousarray(tiles[tiles["level"] == k])
+                self._level_tiles.append((int(sel.size), torch.from_numpy(sel.view(np.uint8).copy()).to(self.dev) if sel.size else None))
+        n, tiles_d = self._level_tiles[l]
+        if n == 0:
+            return
+        nat.check(self.lib.wb_channels_launch(nat.stream_ptr(), nat.ptr(self.img), p.H * p.W, nat.ptr(self.oct),
+                                              p.oct_total, self.wb_dtype, self.batch, nat.ptr(self.levels),
+                                              p.n_levels, nat.ptr(tiles_d), n,
+                                              nat.ptr(self.minmax), max(p.n_oct, 1), nat.ptr(self.taps),
+                                              self.spec.func_id, p.shrink, p.smooth,
+                                              self.cs_sn.ctypes.data_as(C.POINTER(C.c_double)),
+                                              nat.ptr(self.chn), self.chn_stride, None, None, 0),
+                  "wb_channels_launch")
 
     def run_channels(self, rank_dm=None, floats=True):
         self.launch_octaves()

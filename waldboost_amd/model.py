@@ -14,6 +14,7 @@ from . import engine as _engine
 from . import model_pb2
 from .boxes import Boxes, concatenate
 from .channels import channel_pyramid
+from .compare import channel_tensor
 from .training import DTree
 
 # above this many detections per call the compaction, ordering and boxes stay on the GPU
@@ -123,10 +124,10 @@ class Model:
         u, v, ch_image = X.shape
         m, n, ch_cls = self.shape
         assert ch_image == ch_cls, f"Invalid number of channels. Expected {ch_cls} given {ch_image}."
-        xdt = _channel_dtype(X)
         dm = self.device_cascade()
-        eng = _SingleLevel.get(u, v, ch_image, xdt)
-        eng.load(X)
+        Xd, wdt = channel_tensor(X, nat.require_gpu())       # any dtype, compared as NumPy would (compare.py)
+        eng = _SingleLevel.get(u, v, ch_image, np.uint8 if wdt == nat.WB_DTYPE_U8 else np.float32)
+        eng.load(Xd)
         n_det, alive = eng.scan(dm)
         self.n_loc += max(u - m, 0) * max(v - n, 0)
         self.n_weak += int(alive.sum())
@@ -252,14 +253,11 @@ class Model:
         import torch
         n, *shape = X.shape
         assert tuple(shape) == tuple(self.shape), f"Invalid shape of X. Expected {self.shape}, given {shape}"
-        xdt = _channel_dtype(X)
         if n == 0:
             return np.zeros(0, np.float32), np.ones(0, bool)
         dm = self.device_cascade()
         dev = nat.require_gpu()
-        tdt, wdt = (torch.uint8, nat.WB_DTYPE_U8) if xdt == np.uint8 else (torch.float32, nat.WB_DTYPE_F32)
-        Xd = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X))
-        Xd = Xd.to(dev, tdt).contiguous()
+        Xd, wdt = channel_tensor(X, dev)
         H = torch.empty(n, dtype=torch.float32, device=dev)
         mask = torch.empty(n, dtype=torch.uint8, device=dev)
         nat.check(nat.load().wb_samples_predict_launch(nat.stream_ptr(), dm.handle, nat.ptr(Xd), wdt, n, nat.ptr(H),
@@ -311,16 +309,6 @@ class Model:
         except (DecodeError, zlib.error):
             raise ValueError(f"Cannot read model from {filename}")
         return Model.from_proto(proto)
-
-
-def _channel_dtype(X):
-    """Channel images are float32 or uint8 (what channel_pyramid yields; a uint8 value compares
-    against the float32 thresholds as its exact float32 value, like NumPy's promotion).  The
-    reference would compare a float64 X in float64; silently casting X would change results."""
-    dt = str(getattr(X, "dtype", None)).replace("torch.", "")
-    if dt not in ("float32", "uint8"):
-        raise TypeError(f"channel image must be float32 or uint8 (as produced by channel_pyramid), got {dt}")
-    return np.dtype(dt)
 
 
 class _SingleLevel:

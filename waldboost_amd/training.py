@@ -8,6 +8,7 @@ the evaluation runs in a HIP kernel (csrc/wb_cascade.hip: tree_eval_kernel).  ``
 import numpy as np
 
 from . import _native as nat
+from .compare import channel_tensor
 
 
 class DTree:
@@ -68,16 +69,10 @@ class DTree:
         if rs.size == 0:
             return np.empty(0, np.float32)
         u, v, C = X.shape
-        xdt = str(getattr(X, "dtype", None)).replace("torch.", "")
-        if xdt not in ("float32", "uint8"):
-            raise TypeError(f"channel image must be float32 or uint8 (as produced by channel_pyramid), got {xdt}")
-        np_dt, t_dt = (np.uint8, torch.uint8) if xdt == "uint8" else (np.float32, torch.float32)
-        wb_dt = nat.WB_DTYPE_U8 if xdt == "uint8" else nat.WB_DTYPE_F32
         fmax = self.feature[self.node].max(axis=0) if self.node.any() else np.zeros(3, np.int64)
         if rs.min() < 0 or cs.min() < 0 or rs.max() + int(fmax[0]) >= u or cs.max() + int(fmax[1]) >= v or int(fmax[2]) >= C:
             raise IndexError("window feature outside the channel image")
-        Xd = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X, np_dt))
-        Xd = Xd.to(dev, t_dt).contiguous()
+        Xd, wb_dt = channel_tensor(X, dev)        # any dtype, compared as NumPy would (compare.py)
         rd = torch.from_numpy(rs.astype(np.int32)).to(dev)
         cd = torch.from_numpy(cs.astype(np.int32)).to(dev)
         out = torch.empty(rs.size, dtype=torch.float32, device=dev)
@@ -95,16 +90,10 @@ class DTree:
         N, m, n, C = X.shape
         if N == 0:
             return np.zeros(0, "i")
-        xdt = str(getattr(X, "dtype", None)).replace("torch.", "")
-        if xdt not in ("float32", "uint8"):
-            raise TypeError(f"samples must be float32 or uint8 (as produced by channel_pyramid), got {xdt}")
         fmax = self.feature[self.node].max(axis=0) if self.node.any() else np.zeros(3, np.int64)
         if int(fmax[0]) >= m or int(fmax[1]) >= n or int(fmax[2]) >= C:
             raise IndexError("tree feature outside the sample")
-        np_dt, t_dt = (np.uint8, torch.uint8) if xdt == "uint8" else (np.float32, torch.float32)
-        wb_dt = nat.WB_DTYPE_U8 if xdt == "uint8" else nat.WB_DTYPE_F32
-        Xd = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X, np_dt))
-        Xd = Xd.to(dev, t_dt).contiguous()
+        Xd, wb_dt = channel_tensor(X, dev)
         out = torch.empty(N, dtype=torch.int32, device=dev)
         f, t, l, r, p = self._device_arrays(dev)
         nat.check(lib.wb_tree_apply_launch(nat.stream_ptr(), nat.ptr(Xd), wb_dt, N, m, n, C, nat.ptr(f), nat.ptr(t),
