@@ -60,6 +60,18 @@ extern "C" {
  * model.  Available when the model has 4 channels and at most 255 distinct thresholds per channel
  * (WbModelInfo.rank_ok). */
 #define WB_DTYPE_RANK8 2
+/* Image buffers only: the other dtypes the reference's channel_pyramid accepts (channels.py:122 keeps
+ * image.dtype).  All of them are held as float64 elements (exact for these integer types); the code tells the
+ * octave kernel how avg_pool_2's adds wrap (integers wrap modulo 2^bits in the array's dtype, channels.py:61-64)
+ * and the channel kernel how the resize result is cast back (.astype(dtype), channels.py:132: truncation toward
+ * zero for integers; float64 stays float64 and is rounded to float32 by grad_hist's astype("f")).
+ * Their per-octave (min, max) keys are 64-bit: minmax is then uint64 [batch][n_oct][2]. */
+#define WB_DTYPE_F64 3
+#define WB_DTYPE_I8 4
+#define WB_DTYPE_I16 5
+#define WB_DTYPE_U16 6
+#define WB_DTYPE_I32 7
+#define WB_DTYPE_U32 8
 
 /* Channel functions (channel_opts["channels"] of the reference) the channel kernel implements:
  *   WB_CHN_GRAD_HIST       waldboost.channels.grad_hist (n_bins=4)    4 x float32  channels.py:40-52
@@ -156,7 +168,8 @@ int wb_channel_func_info(int channel_func, int *n_channels, int *chn_dtype);
  *   oct      dev  per-image octave buffer for octaves 1..n_oct-1 (octave k at
  *                 oct + b*oct_stride + oct_off[k]); oct_off is a HOST array of n_oct
  *                 element offsets (oct_off[0] ignored)
- *   minmax   dev  uint32 [batch][n_oct][2] order-preserving keys of (min, max)
+ *   minmax   dev  uint32 [batch][n_oct][2] order-preserving keys of (min, max); uint64 [batch][n_oct][2]
+ *                 for WB_DTYPE_F64 and the integer codes
  * uint8 pooling wraps mod 256 before the divide, as the reference does under NumPy
  * (SURVEY S2); float32 pooling is ((a+b)+c)+d then /4. */
 int wb_octaves_launch(void *stream, const void *img, int dtype, int batch, int H, int W,

@@ -14,7 +14,7 @@ import pytest
 import waldboost_amd as wb
 from oracle import wb_oracle as orc
 from waldboost_amd.synth import synth_image, random_tree_arrays
-from util import GOLDEN, golden_meta, oracle_detect, oracle_model, small_cases
+from util import GOLDEN, dtype_cases, golden_meta, oracle_detect, oracle_model, small_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -60,6 +60,29 @@ def test_channel_pyramid_bit_exact_vs_reference_fixture(case):
         assert c.dtype == np.float32 and c.shape == ref.shape, (name, i)
         assert s == rs
         assert np.array_equal(bits(c), bits(ref)), (name, i, np.abs(c - ref).max())
+
+
+@pytest.mark.parametrize("case", list(dtype_cases()), ids=lambda c: c[0])
+def test_channel_pyramid_of_other_image_dtypes_vs_reference_fixture(case):
+    """float64 and integer images keep their dtype through the octaves and the resize (reference channels.py:122,
+    :132): integer octave sums wrap, the resize result is truncated back; every level bit-exact, and a detection
+    on such an image equals the oracle's."""
+    name, img, info, levels = case
+    opts = dict(wb.default_channel_opts, shrink=info["shrink"], n_per_oct=info["n_per_oct"], smooth=info["smooth"])
+    got = list(wb.channels.channel_pyramid(img, opts))
+    assert len(got) == info["n_levels"]
+    for (c, s), ref, rs in zip(got, levels, info["scales"]):
+        assert s == rs and c.dtype == np.float32 and c.shape == ref.shape
+        assert np.array_equal(bits(c), bits(ref))
+    M = random_model(7, 12, 2, opts=opts)
+    # thresholds where the channel values are (these images span very different ranges)
+    vals = np.concatenate([c.reshape(-1) for c, _ in got])
+    rng = np.random.default_rng(5)
+    for w in M.classifier:
+        w.threshold[:] = np.quantile(vals, rng.uniform(0.3, 0.7, w.threshold.size)).astype(np.float32)
+    with np.errstate(over="ignore"):
+        ref = oracle_detect(M, img)
+    assert_same_detections(M.detect_raw(img), ref)
 
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32])

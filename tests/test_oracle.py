@@ -209,3 +209,17 @@ def test_level_plan_geometry_of_the_survey():
     n_loc = sum(max(l["nh"] // 2 - 12, 0) * max(l["nw"] // 2 - 12, 0) for l in p)
     assert n_loc == 3045278
     assert sum(l["nh"] * l["nw"] for l in p) == 13007444
+
+
+@pytest.mark.parametrize("case", list(__import__("util").dtype_cases()), ids=lambda c: c[0])
+def test_oracle_pyramids_of_other_image_dtypes_vs_reference_fixture(case):
+    """float64 and integer images (reference channels.py:122 keeps image.dtype): every level bit-exact."""
+    name, img, info, levels = case
+    assert str(img.dtype) == info["dtype"]
+    opts = dict(shrink=info["shrink"], n_per_oct=info["n_per_oct"], smooth=info["smooth"], channels=orc.grad_hist)
+    with np.errstate(over="ignore"):
+        got = list(orc.channel_pyramid(img, opts))
+    assert len(got) == info["n_levels"]
+    for (c, s), ref, rs in zip(got, levels, info["scales"]):
+        assert s == rs and c.dtype == np.float32 and c.shape == ref.shape
+        assert np.array_equal(c.view(np.uint32), ref.view(np.uint32))

@@ -55,3 +55,14 @@ def f2_cases():
         img = z[f"{name}/image"]
         levels = [z[f"{name}/L{i}"] for i in range(info["n_levels"])]
         yield name, img, info, levels
+
+
+def dtype_cases():
+    """Small grad_hist pyramids of float64 / integer images (tests/golden/make_golden_dtypes.py)."""
+    with open(os.path.join(GOLDEN, "golden_meta_dtypes.json")) as f:
+        meta = json.load(f)["cases"]
+    z = np.load(os.path.join(GOLDEN, "pyramids_dtypes.npz"))
+    for name, info in meta.items():
+        img = z[f"{name}/image"]
+        levels = [z[f"{name}/L{i}"] for i in range(info["n_levels"])]
+        yield name, img, info, levels

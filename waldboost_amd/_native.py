@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WB_NATIVE_LIB") or os.path.join(_HERE, "csrc", "libwaldboost_hip.so")
 
 WB_DTYPE_U8, WB_DTYPE_F32, WB_DTYPE_RANK8 = 0, 1, 2
+WB_DTYPE_F64, WB_DTYPE_I8, WB_DTYPE_I16, WB_DTYPE_U16, WB_DTYPE_I32, WB_DTYPE_U32 = 3, 4, 5, 6, 7, 8
 WB_ERR_INVALID, WB_ERR_HIP, WB_ERR_UNSUPPORTED = -1, -2, -3
 WB_DET_SHARDS = 64
 WB_CHN_GRAD_HIST, WB_CHN_GRAD_HIST_4_U1, WB_CHN_GRAD_MAG_U1, WB_CHN_GRAD_MAG = 0, 1, 2, 3

@@ -34,6 +34,7 @@ struct ChanArgs {
     float c2hi, c2lo;    // cos(pi/2) (fp64: 6.1e-17) likewise
     double tri[11];      // grad_mag: triangle_kernel(5) (float32 values, widened)
     float gm_eps;        // grad_mag: float32(1e-3)
+    int src_int;         // float64-held integer image: the resize result is truncated toward zero (.astype(int dtype))
     int dbg;             // diagnostics (WB_CHAN_DBG): 1 = stop after step 1, 2 = after step 2, 4 = skip the stores
     // optional second output of channels_kernel: the pixels as threshold ranks of one model (WB_DTYPE_RANK8)
     uint8_t *rank;       // [u][v][4] bytes per level, same element offsets as chn; nullptr = none
@@ -103,7 +104,7 @@ template <> struct Src<uint8_t> {
     }
     static __device__ double lo(uint32_t k) { return (double)k; }
     // fp64 result is clipped in fp64, then cast to uint8 by truncation
-    static __device__ float finish(double t, double mn, double mx) {
+    static __device__ float finish(double t, double mn, double mx, int) {
         t = fmin(fmax(t, mn), mx);
         return (float)(int)t;
     }
@@ -117,7 +118,7 @@ template <> struct Src<float> {
     static __device__ bool fast_rows(float, float, float, float, float &) { return false; }
     static __device__ double lo(uint32_t k) { return (double)wb_key_f32(k); }
     // float32 images: zoom stores fp32, then np.clip in fp32
-    static __device__ float finish(double t, double mn, double mx) {
+    static __device__ float finish(double t, double mn, double mx, int) {
         float f = (float)t;
         return fminf(fmaxf(f, (float)mn), (float)mx);
     }
@@ -127,6 +128,39 @@ template <> struct Src<float> {
     }
     static __device__ float dpass(float lo, float hi) { return (float)((double)lo - (double)hi); }
 };
+
+// float64 images, and integer images held as float64 (WB_DTYPE_F64 / WB_DTYPE_I8..U32): zoom in fp64, np.clip in
+// fp64 to the octave's range, .astype(image dtype) -- truncation toward zero for the integer types -- and then the
+// channel function's own astype("f") (reference channels.py:132, :41).  Gradients as for float32 images.
+template <> struct Src<double> {
+    static constexpr bool kFastResample = false;
+    static __device__ bool fast(float, float, float, float, float, float, float, float, float &) { return false; }
+    static __device__ bool fast_rows(float, float, float, float, float &) { return false; }
+    static __device__ double lo(unsigned long long k) {
+        const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+        return __longlong_as_double((long long)b);
+    }
+    static __device__ float finish(double t, double mn, double mx, int src_int) {
+        t = fmin(fmax(t, mn), mx);
+        return (float)(src_int ? trunc(t) : t);
+    }
+    static __device__ float hpass(float a, float b, float c) { return Src<float>::hpass(a, b, c); }
+    static __device__ float dpass(float lo, float hi) { return Src<float>::dpass(lo, hi); }
+};
+
+// the (min, max) an octave's resize result is clipped to, from the order-preserving keys the octave kernel left
+// (32-bit keys for uint8 / float32 images, 64-bit ones for the float64-held dtypes; word 0 holds max(~key))
+template <typename T> __device__ inline void clip_range(const ChanArgs &a, int b, int oct, double &mn, double &mx) {
+    if constexpr (sizeof(T) == 8) {
+        const unsigned long long *mm = reinterpret_cast<const unsigned long long *>(a.minmax) + ((int64_t)b * a.n_oct + oct) * 2;
+        mn = Src<T>::lo(~mm[0]);
+        mx = Src<T>::lo(mm[1]);
+    } else {
+        const uint32_t *mm = a.minmax + ((int64_t)b * a.n_oct + oct) * 2;
+        mn = Src<T>::lo(~mm[0]);
+        mx = Src<T>::lo(mm[1]);
+    }
+}
 
 struct F4 {
     float x, y, z, w;
@@ -403,7 +437,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                             if (!Src<T>::fast((float)b[rb][c][0], (float)b[rb][c][1], (float)b[rb][c][2], (float)b[rb][c][3],
                                               wr0[rb], wr1[rb], wc0f[c], wc1f[c], f))
                                 out[rb][c] = Src<T>::finish(resample_f64((double)b[rb][c][0], (double)b[rb][c][1], (double)b[rb][c][2],
-                                                                         (double)b[rb][c][3], tr, tc[c]), mn, mx);
+                                                                         (double)b[rb][c][3], tr, tc[c]), mn, mx, a.src_int);
                         }
                     }
                 }
@@ -431,7 +465,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
         }
         // RB rows per pass: all their source loads are in flight before the first one is used
         // (one row at a time, the loop was a chain of RH/4 memory latencies per wave)
-        constexpr int RB = 5;
+        constexpr int RB = sizeof(T) == 8 ? 2 : 5;             // (a double pixel is two registers)
         for (int k0 = wave; k0 < RH; k0 += 4 * RB) {
             Tap tr[RB];
             T v00[RB][NCS], v01[RB][NCS], v10[RB][NCS], v11[RB][NCS];
@@ -467,7 +501,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                                               (float)tr[rb].w0, (float)tr[rb].w1, wc0f[c], wc1f[c], out);
                         if (!ok)
                             out = Src<T>::finish(resample_f64((double)v00[rb][c], (double)v01[rb][c], (double)v10[rb][c],
-                                                              (double)v11[rb][c], tr[rb], tc[c]), mn, mx);
+                                                              (double)v11[rb][c], tr[rb], tc[c]), mn, mx, a.src_int);
                     }
                     if (k < RH) R[k * RW + lane + 64 * c] = out;
                 }
@@ -504,7 +538,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             if constexpr (Src<T>::kFastResample)
                 if (!ok) ok = Src<T>::fast((float)a00, (float)a01, (float)a10, (float)a11, (float)tr.w0, (float)tr.w1,
                                            (float)tc.w0, (float)tc.w1, out);
-            if (!ok) out = Src<T>::finish(resample_f64((double)a00, (double)a01, (double)a10, (double)a11, tr, tc), mn, mx);
+            if (!ok) out = Src<T>::finish(resample_f64((double)a00, (double)a01, (double)a10, (double)a11, tr, tc), mn, mx, a.src_int);
             R[k * RW + q] = out;
         }
     }
@@ -532,8 +566,8 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
 
     const T *src = (L.oct == 0) ? (const T *)a.img + (int64_t)b * a.img_stride
                                 : (const T *)a.oct + (int64_t)b * a.oct_stride + L.src_off;
-    const uint32_t *mm = a.minmax + ((int64_t)b * a.n_oct + L.oct) * 2;
-    const double mn = Src<T>::lo(~mm[0]), mx = Src<T>::lo(mm[1]);   // mm[0] holds max(~key)
+    double mn, mx;
+    clip_range<T>(a, b, L.oct, mn, mx);
 
     const int ry0 = S * (u0 - HS) - 1, rx0 = S * (v0 - HS) - 1;
     WB_CSTAMP(0);
@@ -774,8 +808,8 @@ __global__ __launch_bounds__(256) void channels_u1_kernel(ChanArgs a) {
     const int u0 = tile.ty * TU, v0 = tile.tx * TV;
     const T *src = (L.oct == 0) ? (const T *)a.img + (int64_t)b * a.img_stride
                                 : (const T *)a.oct + (int64_t)b * a.oct_stride + L.src_off;
-    const uint32_t *mm = a.minmax + ((int64_t)b * a.n_oct + L.oct) * 2;
-    const double mn = Src<T>::lo(~mm[0]), mx = Src<T>::lo(mm[1]);
+    double mn, mx;
+    clip_range<T>(a, b, L.oct, mn, mx);
     const int ry0 = S * (u0 - HS) - 1, rx0 = S * (v0 - HS) - 1;
     resample_tile<T, G>(a, L, src, mn, mx, ry0, rx0, R, uni, tid);
     __syncthreads();
@@ -968,8 +1002,8 @@ __global__ __launch_bounds__(256) void channels_gm_kernel(ChanArgs a) {
     const int u0 = tile.ty * TU, v0 = tile.tx * TV;
     const T *src = (L.oct == 0) ? (const T *)a.img + (int64_t)b * a.img_stride
                                 : (const T *)a.oct + (int64_t)b * a.oct_stride + L.src_off;
-    const uint32_t *mm = a.minmax + ((int64_t)b * a.n_oct + L.oct) * 2;
-    const double mn = Src<T>::lo(~mm[0]), mx = Src<T>::lo(mm[1]);
+    double mn, mx;
+    clip_range<T>(a, b, L.oct, mn, mx);
     const Tap *__restrict__ rtap = a.taps + L.tap_off;
     const Tap *__restrict__ ctap = rtap + L.nh;
     const bool ident = (L.src_h == L.nh) && (L.src_w == L.nw);
@@ -1003,7 +1037,7 @@ __global__ __launch_bounds__(256) void channels_gm_kernel(ChanArgs a) {
             if constexpr (Src<T>::kFastResample)
                 if (!ok) ok = Src<T>::fast((float)a00[k], (float)a01[k], (float)a10[k], (float)a11[k], (float)tr[k].w0,
                                            (float)tr[k].w1, (float)tc[k].w0, (float)tc[k].w1, out);
-            if (!ok) out = Src<T>::finish(resample_f64((double)a00[k], (double)a01[k], (double)a10[k], (double)a11[k], tr[k], tc[k]), mn, mx);
+            if (!ok) out = Src<T>::finish(resample_f64((double)a00[k], (double)a01[k], (double)a10[k], (double)a11[k], tr[k], tc[k]), mn, mx, a.src_int);
             if (p0 + 256 * k < RH * RW) R[p0 + 256 * k] = out;
         }
     }
@@ -1203,6 +1237,7 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
     a.n_oct = n_oct;
     a.chn = chn;
     a.chn_stride = chn_stride;
+    a.src_int = 0;
     a.rank = rank;
     a.rank_stride = rank_stride;
     a.rank_lut = nullptr;
@@ -1248,7 +1283,11 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
         return launch_dtype<uint8_t, false>(st, grid, a, shrink, smooth != 0);
     }
     if (dtype == WB_DTYPE_F32) return launch_dtype<float, false>(st, grid, a, shrink, smooth != 0);
-    wb_set_error("wb_channels_launch: unsupported dtype %d (uint8 and float32 images only)", dtype);
+    if (dtype == WB_DTYPE_F64 || (dtype >= WB_DTYPE_I8 && dtype <= WB_DTYPE_U32)) {
+        a.src_int = dtype != WB_DTYPE_F64;
+        return launch_dtype<double, false>(st, grid, a, shrink, smooth != 0);
+    }
+    wb_set_error("wb_channels_launch: unsupported image dtype code %d", dtype);
     return WB_ERR_UNSUPPORTED;
 }
 

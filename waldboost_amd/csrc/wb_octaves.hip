@@ -265,6 +265,108 @@ __global__ __launch_bounds__(256) void octaves_tail_kernel(T *oct, int64_t oct_s
     }
 }
 
+// -------------------------------------------------------------------------------------------
+// Every other image dtype the reference accepts (channels.py:122: "dtype = image.dtype"): float64, and the
+// integer types, held as float64 (exact: |v| < 2^53).  avg_pool_2 (channels.py:55-64) adds in the ARRAY's
+// dtype -- integers wrap modulo 2^bits -- divides by 4 in float64 and casts back by truncation; float64 adds
+// ((a+b)+c)+d and divides exactly.  min/max are 64-bit order-preserving keys (word 0: max of ~key, word 1:
+// max of key, atomicMax on zeroed words, like the 32-bit ones).  One plain launch per octave: these are the
+// rare dtypes, correct rather than tuned.
+__device__ inline unsigned long long f64_key(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__device__ inline void wave_minmax64_commit(unsigned long long nlo, unsigned long long hi, unsigned long long *mm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long l2 = __shfl_xor(nlo, o), h2 = __shfl_xor(hi, o);
+        nlo = l2 > nlo ? l2 : nlo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (nlo) atomicMax(mm + 0, nlo);
+        if (hi) atomicMax(mm + 1, hi);
+    }
+}
+
+// wrap an exact integer sum (|s| < 2^36) into the integer type of `bits` bits (two's complement if sgn)
+__device__ inline double wrap_int(double s, int bits, int sgn) {
+    const double m = (double)(1ull << bits);
+    double r = s - floor(s / m) * m;                    // s mod 2^bits, exact (powers of two, small integers)
+    if (sgn && r >= m * 0.5) r -= m;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void minmax_f64_kernel(const double *img, int64_t img_stride, int64_t n, int n_oct,
+                                                         unsigned long long *minmax) {
+    const double *src = img + (int64_t)blockIdx.y * img_stride;
+    unsigned long long nlo = 0, hi = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long k = f64_key(src[i]);
+        nlo = ~k > nlo ? ~k : nlo;
+        hi = k > hi ? k : hi;
+    }
+    wave_minmax64_commit(nlo, hi, minmax + (int64_t)blockIdx.y * n_oct * 2);
+}
+
+// octave k from octave k - 1 (src: sh x sw, dst: oh x ow = floor(sh/2) x floor(sw/2))
+__global__ __launch_bounds__(256) void pool_f64_kernel(const double *src_base, int64_t src_stride, int sw, double *dst_base,
+                                                       int64_t dst_stride, int oh, int ow, int bits, int sgn, int k, int n_oct,
+                                                       unsigned long long *minmax) {
+    const double *src = src_base + (int64_t)blockIdx.y * src_stride;
+    double *dst = dst_base + (int64_t)blockIdx.y * dst_stride;
+    unsigned long long nlo = 0, hi = 0;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (int64_t)oh * ow) {
+        const int r = (int)(i / ow), c = (int)(i - (int64_t)r * ow);
+        const double *p0 = src + (int64_t)(2 * r) * sw + 2 * c;
+        const double a = p0[0], b = p0[sw], cc = p0[1], d = p0[sw + 1];      // [2r,2c], [2r+1,2c], [2r,2c+1], [2r+1,2c+1]
+        double v;
+        if (bits) {
+            // each add wraps in the array's dtype; wrapping once at the end is the same residue
+            v = trunc(wrap_int(((a + b) + cc) + d, bits, sgn) / 4.0);
+        } else {
+            v = (((a + b) + cc) + d) / 4.0;
+        }
+        dst[i] = v;
+        const unsigned long long key = f64_key(v);
+        nlo = ~key;
+        hi = key;
+    }
+    wave_minmax64_commit(nlo, hi, minmax + ((int64_t)blockIdx.y * n_oct + k) * 2);
+}
+
+int launch_octaves_f64(hipStream_t st, const double *img, int dtype, int batch, int H, int W, int64_t img_stride, double *oct,
+                       int64_t oct_stride, const int64_t *oct_off, int n_oct, unsigned long long *minmax) {
+    int bits = 0, sgn = 0;
+    switch (dtype) {
+        case WB_DTYPE_F64: break;
+        case WB_DTYPE_I8: bits = 8; sgn = 1; break;
+        case WB_DTYPE_I16: bits = 16; sgn = 1; break;
+        case WB_DTYPE_U16: bits = 16; break;
+        case WB_DTYPE_I32: bits = 32; sgn = 1; break;
+        case WB_DTYPE_U32: bits = 32; break;
+    }
+    WB_HIP_CHECK(hipMemsetAsync(minmax, 0, sizeof(unsigned long long) * 2 * (size_t)batch * n_oct, st));
+    const int64_t n0 = (int64_t)H * W;
+    int blocks = (int)((n0 + 255) / 256);
+    blocks = blocks > 2048 ? 2048 : blocks;
+    hipLaunchKernelGGL(minmax_f64_kernel, dim3(blocks, batch), dim3(256), 0, st, img, img_stride, n0, n_oct, minmax);
+    int sh = H, sw = W;
+    for (int k = 1; k < n_oct; ++k) {
+        const int oh = sh >> 1, ow = sw >> 1;
+        const double *src = k == 1 ? img : oct + oct_off[k - 1];
+        const int64_t sstride = k == 1 ? img_stride : oct_stride;
+        hipLaunchKernelGGL(pool_f64_kernel, dim3((unsigned)(((int64_t)oh * ow + 255) / 256), batch), dim3(256), 0, st, src, sstride,
+                           sw, oct + oct_off[k], oct_stride, oh, ow, bits, sgn, k, n_oct, minmax);
+        sh = oh;
+        sw = ow;
+    }
+    WB_HIP_CHECK(hipGetLastError());
+    return WB_OK;
+}
+
 template <typename T>
 int launch_octaves(hipStream_t st, const T *img, int batch, int H, int W, int64_t img_stride, T *oct,
                    int64_t oct_stride, const int64_t *oct_off, int n_oct, uint32_t *minmax) {
@@ -318,6 +420,9 @@ extern "C" int wb_octaves_launch(void *stream, const void *img, int dtype, int b
         return launch_octaves<uint8_t>(st, (const uint8_t *)img, batch, H, W, img_stride, (uint8_t *)oct, oct_stride, oct_off, n_oct, minmax);
     if (dtype == WB_DTYPE_F32)
         return launch_octaves<float>(st, (const float *)img, batch, H, W, img_stride, (float *)oct, oct_stride, oct_off, n_oct, minmax);
-    wb_set_error("wb_octaves_launch: unsupported dtype %d (uint8 and float32 images only)", dtype);
+    if (dtype == WB_DTYPE_F64 || (dtype >= WB_DTYPE_I8 && dtype <= WB_DTYPE_U32))
+        return launch_octaves_f64(st, (const double *)img, dtype, batch, H, W, img_stride, (double *)oct, oct_stride, oct_off, n_oct,
+                                  reinterpret_cast<unsigned long long *>(minmax));
+    wb_set_error("wb_octaves_launch: unsupported image dtype code %d", dtype);
     return WB_ERR_UNSUPPORTED;
 }

@@ -24,12 +24,31 @@ _NO_RANKS = bool(os.environ.get("WB_NO_RANKS"))     # diagnostic: float32 channe
 def _torch_dtype(np_dtype):
     import torch
     if not _TORCH_DT:
-        _TORCH_DT.update({np.dtype(np.uint8): torch.uint8, np.dtype(np.float32): torch.float32})
+        _TORCH_DT.update({np.dtype(np.uint8): torch.uint8, np.dtype(np.float32): torch.float32,
+                          np.dtype(np.float64): torch.float64})
     try:
         return _TORCH_DT[np.dtype(np_dtype)]
     except KeyError:
+        raise NotImplementedError(f"dtype {np.dtype(np_dtype)} has no HIP kernel") from None
+
+
+# Image dtypes (reference channels.py:122 keeps image.dtype through the pyramid): uint8 and float32 have their own
+# kernels; float64 and the integer types whose values are exact in float64 are held as float64 on the device, with
+# a code that tells the kernels how avg_pool_2 wraps and how the resize result is cast back (waldboost_hip.h).
+_IMAGE_CODES = {np.dtype(np.uint8): (np.uint8, nat.WB_DTYPE_U8), np.dtype(np.float32): (np.float32, nat.WB_DTYPE_F32),
+                np.dtype(np.float64): (np.float64, nat.WB_DTYPE_F64), np.dtype(np.int8): (np.float64, nat.WB_DTYPE_I8),
+                np.dtype(np.int16): (np.float64, nat.WB_DTYPE_I16), np.dtype(np.uint16): (np.float64, nat.WB_DTYPE_U16),
+                np.dtype(np.int32): (np.float64, nat.WB_DTYPE_I32), np.dtype(np.uint32): (np.float64, nat.WB_DTYPE_U32)}
+
+
+def image_code(np_dtype):
+    """(storage dtype on the device, WB_DTYPE_* code) of an image dtype; NotImplementedError if it has no kernel."""
+    try:
+        return _IMAGE_CODES[np.dtype(np_dtype)]
+    except KeyError:
         raise NotImplementedError(
-            f"image dtype {np.dtype(np_dtype)} has no HIP kernel (uint8 and float32 are supported)") from None
+            f"image dtype {np.dtype(np_dtype)} has no HIP kernel (uint8, float32, float64, int8, int16, uint16, int32 "
+            "and uint32 are supported)") from None
 
 
 def orientation_constants():
@@ -161,8 +180,12 @@ class PyramidEngine:
         self.spec = channels if channels is not None else SPECS["grad_hist"]
         if self.spec.dtype == np.uint8 and self.dtype != np.uint8:
             raise NotImplementedError(f"{self.spec.key} takes 8 bit images (uint8), got {self.dtype}")
-        self.tdtype = _torch_dtype(dtype)
-        self.wb_dtype = nat.WB_DTYPE_U8 if self.dtype == np.uint8 else nat.WB_DTYPE_F32
+        self.store_dtype, self.wb_dtype = image_code(self.dtype)       # (how the image sits in HBM, what the kernels are told)
+        self.store_dtype = np.dtype(self.store_dtype)
+        if self.spec.key != "grad_hist" and self.wb_dtype not in (nat.WB_DTYPE_U8, nat.WB_DTYPE_F32):
+            raise NotImplementedError(f"{self.spec.key} has kernels for uint8 and float32 images, got {self.dtype}")
+        self.tdtype = _torch_dtype(self.store_dtype)
+        self.wide_keys = self.store_dtype == np.float64                # 64-bit (min, max) keys per octave
         self.batch = int(batch)
         self.plan = PyramidPlan(H, W, shrink, n_per_oct, smooth, exact_single=exact_single,
                                 n_chn=self.spec.n_channels, chn_bytes=self.spec.dtype.itemsize)
@@ -175,7 +198,8 @@ class PyramidEngine:
         self.img = self._img_flat[: self.batch * p.H * p.W].view(self.batch, p.H, p.W)
         self._oct_flat = torch.zeros(self.batch * p.oct_total + 16, dtype=self.tdtype, device=dev)
         self.oct = self._oct_flat[: self.batch * p.oct_total].view(self.batch, p.oct_total)
-        self.minmax = torch.zeros((self.batch, max(p.n_oct, 1), 2), dtype=torch.int32, device=dev)
+        self.minmax = torch.zeros((self.batch, max(p.n_oct, 1), 2), dtype=torch.int64 if self.wide_keys else torch.int32,
+                                  device=dev)
         table, total = p.level_table()
         self.chn_stride = int(total)
         self.level_np = table
@@ -199,14 +223,15 @@ class PyramidEngine:
         self.alive = None
         self._casc = {}
         if exact_single:
-            # grad_hist on a bare image: no resize happens, so the clip range is (-inf, +inf)
-            lo = np.array([nat_f32_key(-np.inf)], np.uint32).view(np.int32)[0]
-            hi = np.array([nat_f32_key(np.inf)], np.uint32).view(np.int32)[0]
+            # a channel function on a bare image: no resize happens, so the clip range is (-inf, +inf)
             if self.wb_dtype == nat.WB_DTYPE_U8:
                 lo, hi = 0, 255
-            lo = np.array([~np.uint32(np.array([lo]).astype(np.int64)[0] & 0xFFFFFFFF)], np.uint32).view(np.int32)[0]
-            self.minmax[:, :, 0] = int(lo)   # word 0 stores max(~key), see csrc/wb_octaves.hip
-            self.minmax[:, :, 1] = int(hi)
+            else:
+                lo, hi = int(nat_f32_key(-np.inf)), int(nat_f32_key(np.inf))
+            if self.wide_keys:
+                raise NotImplementedError("channel functions on a bare image take uint8 or float32 arrays")
+            self.minmax[:, :, 0] = int(np.array([~np.uint32(lo)], np.uint32).view(np.int32)[0])   # word 0 stores max(~key), see csrc/wb_octaves.hip
+            self.minmax[:, :, 1] = int(np.array([hi], np.uint32).view(np.int32)[0])
 
     def _alloc_det(self):
         """Sharded detection buffer; det_capacity is the total record capacity, split evenly over
@@ -226,6 +251,8 @@ class PyramidEngine:
         if isinstance(images, np.ndarray):
             if images.dtype != self.dtype:
                 raise TypeError(f"engine built for {self.dtype} images, got {images.dtype}")
+            if images.dtype != self.store_dtype:
+                images = images.astype(self.store_dtype)           # integer types travel as float64 (exact)
             if images.ndim == 2:
                 images = images[None]
             if tuple(images.shape) != want:
