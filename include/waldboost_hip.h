@@ -18,6 +18,8 @@
  *   reference waldboost/fpga/channels.py:5-67 (grad_hist_4_u1, grad_mag_u1) and
  *        waldboost/channels.py:30-37 (grad_mag) as channel_opts["channels"]
  *        -> wb_channels_launch with channel_func = WB_CHN_*
+ *   reference waldboost/channels.py:40-52, :30-37 called directly with non-default arguments
+ *        -> wb_grad_hist_launch, wb_grad_mag_launch
  *   reference waldboost/model.py:62-67,272-283 (Model ctor/append) +
  *        waldboost/training.py:24-31 (DTree.__init__)
  *        -> wb_model_create / wb_model_destroy / wb_model_info
@@ -198,6 +200,19 @@ int wb_channels_launch(void *stream, const void *img, int64_t img_stride, const 
                        const WbTap *taps, int channel_func, int shrink, int smooth, const double *cs_sn,
                        void *chn, int64_t chn_stride, const WbModel *rank_model, uint8_t *rank,
                        int64_t rank_stride);
+
+/* The channel functions called directly on one float32 image (the caller's image.astype("f")) WITH ARGUMENTS
+ * (reference channels.py:40-52 grad_hist(image, n_bins, full, bias) and :30-37 grad_mag(image, norm, eps); with
+ * their default arguments, and inside channel_pyramid, they run in wb_channels_launch).
+ *   wb_grad_hist_launch  cs_sn HOST double[2*n_bins]: cos(theta_k) then sin(theta_k) of np.linspace(0, pi or 2*pi,
+ *                        n_bins+1)[:-1]; bias as float32 (a Python scalar is one under NumPy-2 promotion);
+ *                        out dev float32 [H][W][n_bins]
+ *   wb_grad_mag_launch   n_taps = 0: the plain magnitude (norm None or <= 1); else taps HOST float32[n_taps] =
+ *                        triangle_kernel(norm), eps float32, scratch dev float32[2*H*W]; out dev float32 [H][W] */
+int wb_grad_hist_launch(void *stream, const float *img, int H, int W, int n_bins, int full, float bias,
+                        const double *cs_sn, float *out);
+int wb_grad_mag_launch(void *stream, const float *img, int H, int W, int n_taps, const float *taps, float eps,
+                       float *scratch, float *out);
 
 /* Build the device-side cascade from the reference's tree arrays (all HOST pointers).
  *   node_off  int32[n_stages+1]  first node of each stage's tree in the flat arrays

@@ -46,6 +46,24 @@ def main():
         for i, (c, s) in enumerate(lv):
             assert c.dtype == np.float32
             out[f"{name}/L{i}"] = c
+    # channel functions called directly with non-default arguments (reference channels.py:30-52)
+    from waldboost.channels import grad_mag
+    from waldboost_amd.synth import synth_image
+    fimgs = {"u8": synth_image(61, 83, 31), "f32": synth_image(50, 70, 32, np.float32)}
+    calls = [("grad_hist", dict(n_bins=6, full=True, bias=3)), ("grad_hist", dict(n_bins=9, full=False, bias=0.5)),
+             ("grad_hist", dict(n_bins=1)), ("grad_hist", dict(n_bins=4, full=True)), ("grad_mag", dict(norm=None)),
+             ("grad_mag", dict(norm=1)), ("grad_mag", dict(norm=3, eps=0.01)), ("grad_mag", dict(norm=8)),
+             ("grad_mag", dict(norm=30, eps=1.0))]
+    fout, fmeta = {}, []
+    for k, im in fimgs.items():
+        fout[f"image/{k}"] = im
+        for j, (fn, kw) in enumerate(calls):
+            r = (grad_hist if fn == "grad_hist" else grad_mag)(im, **kw)
+            assert r.dtype == np.float32
+            fout[f"{k}/{j}"] = r
+            fmeta.append(dict(image=k, index=j, func=fn, kwargs=kw, shape=list(r.shape)))
+    np.savez_compressed(os.path.join(HERE, "chanfunc_args.npz"), **fout)
+    meta["chanfunc_args"] = fmeta
     np.savez_compressed(os.path.join(HERE, "pyramids_dtypes.npz"), **out)
     with open(os.path.join(HERE, "golden_meta_dtypes.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

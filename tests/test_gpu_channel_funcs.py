@@ -241,8 +241,8 @@ def test_grad_mag_on_a_bare_image(dtype):
         got = wb.channels.grad_mag(img)
         ref = orc.grad_mag(img)
         assert got.shape == ref.shape and np.array_equal(bits(got), bits(ref))
-    with pytest.raises(NotImplementedError):
-        wb.channels.grad_mag(img, norm=3)
+    for kw in (dict(norm=3), dict(norm=None), dict(norm=7, eps=0.25)):      # other arguments: the plain kernels
+        assert np.array_equal(bits(wb.channels.grad_mag(img, **kw)), bits(orc.grad_mag(img, **kw)))
 
 
 def test_grad_mag_detect_vs_reference_fixture():
@@ -260,3 +260,21 @@ def test_grad_mag_detect_vs_reference_fixture():
     assert np.array_equal(res["level"], det["level"]) and np.array_equal(res["r"], det["r"]) and np.array_equal(res["c"], det["c"])
     assert np.array_equal(bits(res["scores"]), bits(det["score"]))
     assert np.array_equal(bits(res["boxes"]), bits(np.stack([det["x1"], det["y1"], det["x2"], det["y2"]], 1)))
+
+
+@pytest.mark.parametrize("case", list(__import__("util").chanfunc_arg_cases()), ids=lambda c: c[0])
+def test_channel_functions_with_arguments_vs_reference_fixture(case):
+    """grad_hist(image, n_bins, full, bias) / grad_mag(image, norm, eps) called directly (reference channels.py:30-52)."""
+    import waldboost_amd as wb
+    name, img, func, kwargs, ref = case
+    got = getattr(wb.channels, func)(img, **kwargs)
+    assert got.dtype == np.float32 and got.shape == ref.shape
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_channel_function_arguments_that_would_change_the_result_dtype():
+    import waldboost_amd as wb
+    img = np.zeros((20, 30), np.uint8)
+    with pytest.raises(NotImplementedError):
+        wb.channels.grad_hist(img, bias=np.float64(1.0))          # float64 scalar: the reference's result is float64
+    assert wb.channels.grad_hist(img, n_bins=3, bias=np.float32(1.0)).shape == (20, 30, 3)

@@ -223,3 +223,11 @@ def test_oracle_pyramids_of_other_image_dtypes_vs_reference_fixture(case):
     for (c, s), ref, rs in zip(got, levels, info["scales"]):
         assert s == rs and c.dtype == np.float32 and c.shape == ref.shape
         assert np.array_equal(c.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("case", list(__import__("util").chanfunc_arg_cases()), ids=lambda c: c[0])
+def test_oracle_channel_functions_with_arguments_vs_reference_fixture(case):
+    name, img, func, kwargs, ref = case
+    got = getattr(orc, func)(img, **kwargs)
+    assert got.dtype == np.float32 and got.shape == ref.shape
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

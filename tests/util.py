@@ -66,3 +66,12 @@ def dtype_cases():
         img = z[f"{name}/image"]
         levels = [z[f"{name}/L{i}"] for i in range(info["n_levels"])]
         yield name, img, info, levels
+
+
+def chanfunc_arg_cases():
+    """grad_hist / grad_mag called with non-default arguments on two small images (make_golden_dtypes.py)."""
+    with open(os.path.join(GOLDEN, "golden_meta_dtypes.json")) as f:
+        meta = json.load(f)["chanfunc_args"]
+    z = np.load(os.path.join(GOLDEN, "chanfunc_args.npz"))
+    for m in meta:
+        yield f"{m['func']}-{m['image']}-{m['index']}", z[f"image/{m['image']}"], m["func"], m["kwargs"], z[f"{m['image']}/{m['index']}"]

@@ -4,13 +4,16 @@
 ``(chns[u,v,C], scale)`` pairs (reference channels.py:111-146), computed by the fused HIP
 kernels in csrc/wb_channels.hip.  Channel functions with a kernel:
 
-  ``grad_hist(image)``            reference channels.py:40-52, default arguments
-                                  (n_bins=4, full=False, bias=0)          -> float32 [H,W,4]
-  ``grad_mag(image)``             reference channels.py:30-37, default arguments
-                                  (norm=5, eps=1e-3)                      -> float32 [H,W,1]
+  ``grad_hist(image, n_bins, full, bias)``   reference channels.py:40-52        -> float32 [H,W,n_bins]
+  ``grad_mag(image, norm, eps)``             reference channels.py:30-37        -> float32 [H,W,1]
+                                  (inside a pyramid they run with their default arguments, as the reference's
+                                  ``channels(im)`` call does, in the fused kernels; called directly with other
+                                  arguments, in the plain kernels of csrc/wb_chanfunc.hip)
   ``fpga.grad_hist_4_u1(image)``  reference fpga/channels.py:29-53        -> uint8   [H,W,4]
   ``fpga.grad_mag_u1(image)``     reference fpga/channels.py:56-67        -> uint8   [H,W,1]
 """
+import ctypes as C
+
 import numpy as np
 
 from . import _native as nat
@@ -39,20 +42,72 @@ def _on_bare_image(image, spec):
     return eng.read_level(0, 0)
 
 
+def _python_scalar_f32(x, what):
+    """float32 value of a scalar that NumPy treats as weak next to a float32 array (Python int / float / bool, or a
+    float32 / float16 / small-integer NumPy scalar): the reference's `array - bias` / `array + eps` then stay float32.
+    A float64 / int64 NumPy scalar would turn the reference's result into float64 -- not provided here."""
+    if type(x) in (bool, int, float) or np.result_type(np.float32, x) == np.float32:     # (np.float64 subclasses float)
+        return float(np.float32(x))
+    raise NotImplementedError(f"{what}={x!r} ({type(x).__name__}) makes the reference compute in float64; pass a Python "
+                              "scalar or a float32")
+
+
 def grad_hist(image, n_bins=4, full=False, bias=0):
-    """4 unsigned oriented-gradient channels of a 2-D image -> float32 [H,W,4]."""
-    if n_bins != 4 or full or bias != 0:
-        raise NotImplementedError("the HIP grad_hist kernel implements the defaults n_bins=4, full=False, bias=0")
+    """Oriented-gradient channels of a 2-D image -> float32 [H,W,n_bins] (reference channels.py:40-52): n_bins
+    orientations over pi (full=False: magnitudes) or 2*pi (full=True: signed), less `bias`, clamped at 0."""
+    import torch
     _validate_image(image)
-    return _on_bare_image(image.astype("f"), SPECS["grad_hist"])
+    if n_bins == 4 and not full and type(bias) in (bool, int, float) and bias == 0:
+        return _on_bare_image(image.astype("f"), SPECS["grad_hist"])
+    n_bins = int(n_bins)
+    if not 1 <= n_bins <= 32:
+        raise NotImplementedError(f"grad_hist: n_bins={n_bins} has no kernel (1..32)")
+    b32 = _python_scalar_f32(bias, "bias")
+    img = np.ascontiguousarray(image.astype("f"))
+    H, W = img.shape
+    if H < 1 or W < 1:
+        return np.empty((H, W, n_bins), np.float32)
+    dev = nat.require_gpu()
+    theta = np.linspace(0, 2 * np.pi if full else np.pi, n_bins + 1)          # reference channels.py:43-46
+    cs_sn = np.concatenate([np.cos(theta[:-1]), np.sin(theta[:-1])]).astype(np.float64)
+    d = torch.from_numpy(img).to(dev)
+    out = torch.empty((H, W, n_bins), dtype=torch.float32, device=dev)
+    nat.check(nat.load().wb_grad_hist_launch(nat.stream_ptr(), nat.ptr(d), H, W, n_bins, int(bool(full)), b32,
+                                             cs_sn.ctypes.data_as(C.POINTER(C.c_double)), nat.ptr(out)), "wb_grad_hist_launch")
+    return out.cpu().numpy()
+
+
+def triangle_kernel(n):
+    """reference channels.py:11-13."""
+    H = (np.r_[:n + 1, n - 1:-1:-1] + 1).astype("f")
+    return H / H.sum()
 
 
 def grad_mag(image, norm=5, eps=1e-3):
-    """Gradient magnitude divided by its 11-tap-triangle-filtered self -> float32 [H,W,1]."""
-    if norm != 5 or eps != 1e-3:
-        raise NotImplementedError("the HIP grad_mag kernel implements the defaults norm=5, eps=1e-3")
+    """Gradient magnitude, divided by its triangle-filtered self + eps when norm > 1 -> float32 [H,W,1]
+    (reference channels.py:30-37)."""
+    import torch
     _validate_image(image)
-    return _on_bare_image(image.astype("f"), SPECS["grad_mag"])
+    if norm == 5 and type(eps) is float and eps == 1e-3:
+        return _on_bare_image(image.astype("f"), SPECS["grad_mag"])
+    img = np.ascontiguousarray(image.astype("f"))
+    H, W = img.shape
+    if H < 1 or W < 1:
+        return np.empty((H, W, 1), np.float32)
+    taps = None
+    if norm is not None and norm > 1:
+        taps = np.ascontiguousarray(triangle_kernel(int(norm)), np.float32)
+        if taps.size > 127:
+            raise NotImplementedError(f"grad_mag: norm={norm} has no kernel (up to 63)")
+        e32 = _python_scalar_f32(eps, "eps")
+    dev = nat.require_gpu()
+    d = torch.from_numpy(img).to(dev)
+    out = torch.empty((H, W), dtype=torch.float32, device=dev)
+    scratch = torch.empty((2, H, W), dtype=torch.float32, device=dev) if taps is not None else None
+    nat.check(nat.load().wb_grad_mag_launch(nat.stream_ptr(), nat.ptr(d), H, W, 0 if taps is None else int(taps.size),
+                                            None if taps is None else taps.ctypes.data_as(C.POINTER(C.c_float)),
+                                            0.0 if taps is None else e32, nat.ptr(scratch), nat.ptr(out)), "wb_grad_mag_launch")
+    return out.cpu().numpy()[..., None]
 
 
 def grad_hist_4_u1(image):
