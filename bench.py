@@ -225,10 +225,17 @@ def main():
 
     gath = comm = None
     if world > 1:
-        gath = [DetectionGatherer(e.detb) for e in engines]
+        # the gathered prefix is sized from what the workload produces (2x the fullest image set, agreed over the
+        # ranks), not from the buffer's capacity: a few hundred KB per rank instead of the whole detection buffer
+        most = torch.tensor([max(int(e.detb.counts.sum().item()) for e in engines)], dtype=torch.int64,
+                            device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(most, op=dist.ReduceOp.MAX)
+        rows = max(1024, 2 * int(most.item()))
+        gath = [DetectionGatherer(rows, engines[0].dev) for e in engines]
         comm = torch.cuda.Stream()
         ev_done = [torch.cuda.Event() for _ in engines]      # step i's kernels finished
         ev_comm = [torch.cuda.Event() for _ in engines]      # step i's gather finished
+        packs = [None] * len(engines)
 
     n_streams = max(1, min(args.streams, P))
     lanes = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream()]
@@ -246,10 +253,11 @@ def main():
                     st.wait_event(ev_comm[j])                # buffer j free again
                 steps[j]()
                 if world > 1:
+                    packs[j] = engines[j].pack()             # valid records back to back behind a header (one tiny launch)
                     ev_done[j].record(st)
                     with torch.cuda.stream(comm):
                         comm.wait_event(ev_done[j])
-                        gath[j].gather(engines[j].detb)
+                        gath[j].gather(packs[j])
                         ev_comm[j].record(comm)
         for st in lanes:
             if st is not main:
@@ -285,10 +293,10 @@ def main():
         it = max(20, min(args.steps, 100))
         kern["octaves_ms"] = event_time_ms(e.launch_octaves, it, torch)
         kern["channels_ms"] = event_time_ms(lambda: e.launch_channels(dm if fused else None, floats=not fused), it, torch)
-        kern["cascade_ms"] = event_time_ms(lambda: e.run_cascade(dm, ranks=fused), it, torch)   # counter reset + tile kernel + statistics reduction
-        # the dominant kernel alone, as rocprofv3 sees it: cascade_tile_kernel without its follow-up reduction
-        # (the counters are not reset in this loop; records past the capacity are dropped, the work is the same)
-        kern["cascade_tile_ms"] = event_time_ms(lambda: e.launch_cascade(dm, reduce=False, ranks=fused), it, torch)
+        kern["cascade_ms"] = event_time_ms(lambda: e.run_cascade(dm, ranks=fused), it, torch)   # counter reset + tile kernel
+        # the tile kernel alone, as rocprofv3 sees it (the counters are not reset in this loop; records past the
+        # capacity are dropped, the work is the same)
+        kern["cascade_tile_ms"] = event_time_ms(lambda: e.launch_cascade(dm, ranks=fused), it, torch)
         e.run_cascade(dm, ranks=fused)
         ab = plan.algorithmic_bytes(1)
         name = "channels_kernel" if kern["channels_ms"] >= kern["cascade_tile_ms"] else "cascade_kernel"
@@ -341,7 +349,7 @@ def main():
                        "launch": "eager" if args.no_graph else "hipGraph replay", "only": args.only,
                        "channels_in_hbm": "uint8 threshold ranks of the cascade (WB_DTYPE_RANK8)" if fused else spec.dtype.name,
                        "streams": n_streams, "pool": P,
-                       "collective": "all_gather of detection prefix per step (side stream)" if world > 1 else "none"},
+                       "collective": "all_gather of the packed detection prefix per step (side stream)" if world > 1 else "none"},
             "mpixels_per_s": world * args.steps * B * H * W / dt / 1e6,
             "images_per_s": world * args.steps * B / dt,
             "pipeline_roofline_frac": (windows / dt) * (ab["total"] / n_loc) / (HBM_PEAK_GBS * 1e9 * world),

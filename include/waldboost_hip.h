@@ -171,7 +171,7 @@ int wb_channel_func_info(int channel_func, int *n_channels, int *chn_dtype);
  *                 oct + b*oct_stride + oct_off[k]); oct_off is a HOST array of n_oct
  *                 element offsets (oct_off[0] ignored)
  *   minmax   dev  uint32 [batch][n_oct][2] order-preserving keys of (min, max); uint64 [batch][n_oct][2]
- *                 for WB_DTYPE_F64 and the integer codes
+ *                 for WB_DTYPE_F64 and the integer codes.  ACCUMULATED into (atomic max): the caller zeroes it
  * uint8 pooling wraps mod 256 before the divide, as the reference does under NumPy
  * (SURVEY S2); float32 pooling is ((a+b)+c)+d then /4. */
 int wb_octaves_launch(void *stream, const void *img, int dtype, int batch, int H, int W,
@@ -240,20 +240,14 @@ int wb_model_info(const WbModel *model, WbModelInfo *info);
  *   det           dev WbDet[WB_DET_SHARDS][shard_capacity]; det_count dev uint32[WB_DET_SHARDS]:
  *                 survivors per shard (a count may exceed shard_capacity: the records beyond it
  *                 are dropped, the count stays exact -- grow the buffer and launch again)
- *   tile_csr      dev int32[n_levels + 1 + n_tiles]: for each level the range [start, end) into
- *                 the trailing list of tile indices that belong to it (tiles grouped by level)
- *   tile_hist     dev uint32 [batch][n_tiles][n_stages] scratch: per-workgroup alive counts,
- *                 fully overwritten (no zeroing needed)
- *   alive         dev uint32 [batch][n_levels][n_stages]: windows entering each stage, summed
- *                 over the level's tiles by a small follow-up kernel; overwritten.  NULL = skip that
- *                 kernel (the per-tile counts in tile_hist are still written)
- * det_count is ACCUMULATED into: the caller zeroes it.  Record order is unspecified; sort by
+ *   alive         dev uint32 [batch][n_levels][n_stages]: windows entering each stage (the reference's n_weak
+ *                 is its sum, n_loc the sum of column 0: model.py:248,252); NULL = no statistics
+ * det_count and alive are ACCUMULATED into: the caller zeroes them.  Record order is unspecified; sort by
  * (image, level, r, c) to obtain the reference order. */
 int wb_cascade_launch(void *stream, const WbModel *model, const void *chn, int chn_dtype,
                       int64_t chn_stride, int batch, const WbLevel *levels, int n_levels,
-                      const WbTile *tiles, const int32_t *tile_csr, int n_tiles, WbDet *det,
-                      uint32_t *det_count, uint32_t shard_capacity, uint32_t *tile_hist,
-                      uint32_t *alive);
+                      const WbTile *tiles, int n_tiles, WbDet *det, uint32_t *det_count,
+                      uint32_t shard_capacity, uint32_t *alive);
 
 /* The valid records of all shards of a detection buffer (as wb_cascade_launch fills it), packed back to back:
  *   packed  dev int32, 16-byte aligned: a 4-word header {valid records in all shards, fullest shard's count

@@ -11,7 +11,6 @@ import torch.multiprocessing as mp
 
 from waldboost_amd import _native as nat
 from waldboost_amd.distributed import DetectionGatherer, agree_capacity, gather_records, reduce_alive, shard_range
-from waldboost_amd.engine import DetBuffer
 
 
 def test_shard_range_partitions_contiguously():
@@ -35,27 +34,21 @@ def _fake_detections(rank, n_img):
     return d
 
 
-def _fill(detb, recs, rng):
-    """Scatter records over the shards the way concurrent workgroups would."""
-    shard = rng.integers(0, detb.NS, recs.size)
-    counts = np.zeros(detb.NS, np.int32)
-    buf = detb.recs.view(detb.NS, detb.cap, 4)
-    raw = torch.from_numpy(recs.view(np.int32).reshape(-1, 4).copy())
-    for i, s in enumerate(shard):
-        buf[s, counts[s]] = raw[i]
-        counts[s] += 1
-    detb.counts.copy_(torch.from_numpy(counts))
+def _packed(recs, cap_rows, shard_cap=32):
+    """What wb_det_pack_launch leaves on a rank: a 4-word header, then the valid records back to back."""
+    out = torch.zeros((1 + cap_rows, 4), dtype=torch.int32)
+    out[0] = torch.tensor([recs.size, min(recs.size, shard_cap), min(recs.size, cap_rows), shard_cap], dtype=torch.int32)
+    out[1:1 + recs.size] = torch.from_numpy(recs.view(np.int32).reshape(-1, 4).copy())
+    return out
 
 
 def _worker(rank, world, port, images_per_rank, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        detb = DetBuffer(32, torch.device("cpu"))
         recs = _fake_detections(rank, images_per_rank[rank])
-        _fill(detb, recs, np.random.default_rng(rank))
-        g = DetectionGatherer(detb)
-        g.gather(detb)
+        g = DetectionGatherer(256, torch.device("cpu"))           # prefix: 256 records per rank, not the buffer
+        g.gather(_packed(recs, 1024))
         merged = g.merged(images_per_rank)
         q.put((rank, merged.tobytes()))
     finally:
@@ -95,15 +88,18 @@ def test_gather_and_merge_world_size_2():
         assert sorted(got["score"].tolist()) == sorted(want["score"].tolist())
 
 
-def test_overflowing_shard_is_reported():
-    detb = DetBuffer(4, torch.device("cpu"))
-    detb.counts[3] = 9
+def test_overflowing_shard_or_short_prefix_is_reported():
     class G(DetectionGatherer):
-        def __init__(self, detb):
-            self.world, self.NS, self.cap, self.rows = 1, detb.NS, detb.cap, detb.buf.shape[0]
-            self.recv = detb.buf.clone()
+        def __init__(self, packed, rows):
+            self.world, self.rows, self.recv = 1, rows, packed[: 1 + rows].clone()
+    recs = _fake_detections(0, 1)
+    over = _packed(recs, 1024)
+    over[0, 1] = 99                                      # fullest shard beyond its capacity of 32
     with pytest.raises(OverflowError):
-        G(detb).merged([1])
+        G(over, 1024).merged([1])
+    with pytest.raises(OverflowError):
+        G(_packed(recs, 1024), 64).merged([1])           # 150 detections, prefix of 64
+    assert G(_packed(recs, 1024), 256).merged([1]).size == recs.size
 
 
 # ------------------------------------------------------------------------------ the end-of-batch exchange

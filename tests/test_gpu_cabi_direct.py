@@ -92,15 +92,13 @@ def test_pyramid_and_cascade_through_the_raw_abi():
                                        C.c_int(0), C.c_int(2), C.c_int(1), cs_sn.ctypes.data_as(C.POINTER(C.c_double)),
                                        P(chn.data_ptr()), C.c_int64(chn_total), None, None, C.c_int64(0)))
     tiles = plan.casc_tiles(12, 12, info.tile_rows, info.tile_cols)
-    csr = plan.tile_csr(tiles, plan.n_levels)
-    tiles_d, csr_d = up(tiles), torch.from_numpy(csr).to(dev)
+    tiles_d = up(tiles)
     cap, T = 4096, len(thetas)
-    det = torch.zeros((16 + 64 * cap, 4), dtype=torch.int32, device=dev)
-    hist = torch.empty((tiles.size, T), dtype=torch.int32, device=dev)
-    alive = torch.empty((1, plan.n_levels, T), dtype=torch.int32, device=dev)
+    det = torch.zeros((16 + 64 * cap, 4), dtype=torch.int32, device=dev)          # the caller zeroes the counters ...
+    alive = torch.zeros((1, plan.n_levels, T), dtype=torch.int32, device=dev)    # ... and the statistics (accumulated into)
     _check(lib, lib.wb_cascade_launch(st, h, P(chn.data_ptr()), C.c_int(1), C.c_int64(chn_total), C.c_int(1), P(levels_d.data_ptr()),
-                                      C.c_int(plan.n_levels), P(tiles_d.data_ptr()), P(csr_d.data_ptr()), C.c_int(tiles.size),
-                                      P(det[16:].data_ptr()), P(det.data_ptr()), C.c_uint32(cap), P(hist.data_ptr()), P(alive.data_ptr())))
+                                      C.c_int(plan.n_levels), P(tiles_d.data_ptr()), C.c_int(tiles.size),
+                                      P(det[16:].data_ptr()), P(det.data_ptr()), C.c_uint32(cap), P(alive.data_ptr())))
     torch.cuda.synchronize()
     d = _records(det.cpu().numpy(), cap)
     otrees = [orc.make_tree(*tr) for tr in trees]
@@ -119,10 +117,10 @@ def test_pyramid_and_cascade_through_the_raw_abi():
                                        C.c_int(0), C.c_int(2), C.c_int(1), cs_sn.ctypes.data_as(C.POINTER(C.c_double)),
                                        None, C.c_int64(chn_total), h, P(rank.data_ptr()), C.c_int64(chn_total)))
     det2 = torch.zeros((16 + 64 * cap, 4), dtype=torch.int32, device=dev)
-    alive2 = torch.empty((1, plan.n_levels, T), dtype=torch.int32, device=dev)
+    alive2 = torch.zeros((1, plan.n_levels, T), dtype=torch.int32, device=dev)
     _check(lib, lib.wb_cascade_launch(st, h, P(rank.data_ptr()), C.c_int(2), C.c_int64(chn_total), C.c_int(1), P(levels_d.data_ptr()),
-                                      C.c_int(plan.n_levels), P(tiles_d.data_ptr()), P(csr_d.data_ptr()), C.c_int(tiles.size),
-                                      P(det2[16:].data_ptr()), P(det2.data_ptr()), C.c_uint32(cap), P(hist.data_ptr()), P(alive2.data_ptr())))
+                                      C.c_int(plan.n_levels), P(tiles_d.data_ptr()), C.c_int(tiles.size),
+                                      P(det2[16:].data_ptr()), P(det2.data_ptr()), C.c_uint32(cap), P(alive2.data_ptr())))
     packed = torch.zeros((1 + 64 * cap, 4), dtype=torch.int32, device=dev)
     _check(lib, lib.wb_det_pack_launch(st, P(det2[16:].data_ptr()), P(det2.data_ptr()), C.c_uint32(cap), P(packed.data_ptr()),
                                        C.c_uint32(64 * cap)))
@@ -142,5 +140,5 @@ def test_pyramid_and_cascade_through_the_raw_abi():
     assert np.array_equal(boxes.cpu().numpy().view(np.uint32), ref["boxes"].view(np.uint32))
     _check(lib, lib.wb_model_destroy(h))
     # error reporting stays on the C side of the boundary
-    assert lib.wb_cascade_launch(st, None, None, 1, 0, 1, None, 1, None, None, 1, None, None, 0, None, None) != 0
+    assert lib.wb_cascade_launch(st, None, None, 1, 0, 1, None, 1, None, 1, None, None, 0, None) != 0
     assert b"null pointer" in lib.wb_last_error()

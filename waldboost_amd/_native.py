@@ -54,8 +54,8 @@ SYMBOLS = {
     "wb_model_create": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "wb_model_destroy": (C.c_int, [_P]),
     "wb_model_info": (C.c_int, [_P, C.POINTER(WbModelInfo)]),
-    "wb_cascade_launch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P,
-                                    C.c_uint32, _P, _P]),
+    "wb_cascade_launch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P,
+                                    C.c_uint32, _P]),
     "wb_tree_eval_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P, _P, _P, _P, _P,
                                       C.c_int, _P]),
     "wb_gather_samples_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),

@@ -199,6 +199,7 @@ def channel_pyramid(image, channel_opts):
             # first level -- or the (cached, shared) engine has served another image since the last one was
             # yielded: bring this generator's image and octaves back
             eng.load_images(image)
+            eng.reset_step(None, octaves=True)
             eng.launch_octaves()
             mine = eng.epoch
         eng.launch_level(l)

@@ -51,9 +51,7 @@ struct CascArgs {
     WbDet *det;
     uint32_t *det_count;
     uint32_t det_cap;           // per shard
-    uint32_t *tile_hist;        // [batch][n_tiles][T] scratch: each workgroup's per-stage alive counts
-    uint32_t *alive;            // [batch][n_levels][T] written by the reduction kernel
-    const int32_t *tile_csr;    // [n_levels + 1] starts, then [n_tiles] tile indices grouped by level
+    uint32_t *alive;            // [batch][n_levels][T], accumulated into (nullptr: no statistics)
     int n_tiles;
     int spar_wg;                // the whole tile goes stage-parallel after phase A when it holds at most this many windows
     int spar[4];                // stage-parallel tail entry: (t >= spar[0] && n <= spar[1]) || (t >= spar[2] && n <= spar[3])
@@ -565,10 +563,16 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
         for (int w = 0; w < WAVES; ++w) total += wcnt[w];
         wg_base = total ? atomicAdd(a.det_count + shard, total) : 0u;
     }
-    // per-stage alive counts of this tile: a private row, plain coalesced stores (atomics on the
-    // shared [level][stage] counters made every wave of every tile queue up behind each other)
-    uint32_t *th = a.tile_hist + ((int64_t)b * a.n_tiles + blockIdx.x) * a.T;
-    for (int t = tid; t < T; t += NT) th[t] = hist[t];
+    // per-stage alive counts of this tile -> alive[image][level][stage]: one fire-and-forget atomic per stage the
+    // tile reached, once per workgroup (the workgroup's waves have summed in LDS; an atomic per wave and stage made
+    // every wave of every tile queue up behind the others')
+    if (a.alive) {
+        uint32_t *al = a.alive + ((int64_t)b * a.n_levels + tile_d.level) * a.T;
+        for (int t = tid; t < T; t += NT) {
+            const uint32_t c = hist[t];
+            if (c) atomicAdd(al + t, c);
+        }
+    }
     __syncthreads();
     WB_STAMP(6);
     if (n_q > 0) {
@@ -610,7 +614,7 @@ struct GenArgs {
     WbDet *det;
     uint32_t *det_count;
     uint32_t det_cap;
-    uint32_t *tile_hist;
+    uint32_t *alive;
 };
 
 __global__ __launch_bounds__(256) void cascade_generic_kernel(GenArgs a) {
@@ -658,8 +662,11 @@ __global__ __launch_bounds__(256) void cascade_generic_kernel(GenArgs a) {
     __syncthreads();
     const uint32_t shard = blockIdx.x % WB_DET_SHARDS;
     if (tid == 0) base_slot = n_list ? atomicAdd(a.det_count + shard, n_list) : 0u;
-    uint32_t *th_row = a.tile_hist + ((int64_t)b * a.n_tiles + blockIdx.x) * a.T;
-    for (int t = tid; t < a.T; t += 256) th_row[t] = hist[t];
+    if (a.alive) {
+        uint32_t *al = a.alive + ((int64_t)b * a.n_levels + tile_d.level) * a.T;
+        for (int t = tid; t < a.T; t += 256)
+            if (hist[t]) atomicAdd(al + t, hist[t]);
+    }
     __syncthreads();
     if ((uint32_t)tid < n_list) {
         uint2 e = list[tid];
@@ -673,35 +680,6 @@ __global__ __launch_bounds__(256) void cascade_generic_kernel(GenArgs a) {
             d.score = __uint_as_float(e.y);
             a.det[(size_t)shard * a.det_cap + slot] = d;
         }
-    }
-}
-
-// alive[b][level][t] = sum over the level's tiles of tile_hist[b][tile][t]; grid (n_levels, batch),
-// 1024 threads = 16 groups x 64 stages: group g sums tiles lo+g, lo+g+16, ... (independent loads,
-// several in flight), then the 16 partial sums meet in LDS.
-__global__ __launch_bounds__(1024) void alive_reduce_kernel(const uint32_t *tile_hist, const int32_t *tile_csr,
-                                                             int n_levels, int n_tiles, int T, uint32_t *alive) {
-    __shared__ uint32_t part[16][64];
-    const int level = blockIdx.x, b = blockIdx.y;
-    const int lo = tile_csr[level], hi = tile_csr[level + 1];
-    const int32_t *order = tile_csr + n_levels + 1;
-    const int x = threadIdx.x & 63, g = threadIdx.x >> 6;
-    for (int t0 = 0; t0 < T; t0 += 64) {
-        const int t = t0 + x;
-        uint32_t acc = 0;
-        if (t < T) {
-#pragma unroll 4
-            for (int j = lo + g; j < hi; j += 16) acc += tile_hist[((int64_t)b * n_tiles + order[j]) * T + t];
-        }
-        part[g][x] = acc;
-        __syncthreads();
-        if (g == 0 && t < T) {
-            uint32_t s = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) s += part[k][x];
-            alive[((int64_t)b * n_levels + level) * T + t] = s;
-        }
-        __syncthreads();
     }
 }
 
@@ -846,9 +824,6 @@ int launch_depth(hipStream_t st, dim3 grid, const CascArgs &a, int rpw, int wave
             hipLaunchKernelGGL((cascade_tile_kernel<D, R, W, true>), grid, dim3(W * 64), lds, st, a, a.stages);  \
         else                                                                                                \
             hipLaunchKernelGGL((cascade_tile_kernel<D, R, W, false>), grid, dim3(W * 64), lds, st, a, a.stages); \
-        if (a.T > 0 && a.alive)                                                                             \
-            hipLaunchKernelGGL(alive_reduce_kernel, dim3(a.n_levels, grid.y), dim3(1024),                          \
-                               0, st, a.tile_hist, a.tile_csr, a.n_levels, a.n_tiles, a.T, a.alive);         \
         WB_HIP_CHECK(hipGetLastError());                                                                    \
         return WB_OK;                                                                                       \
     }
@@ -890,11 +865,9 @@ int wb_cascade_prepare(int depth, int rpw, int waves) {
 
 extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void *chn, int chn_dtype,
                                  int64_t chn_stride, int batch, const WbLevel *levels, int n_levels,
-                                 const WbTile *tiles, const int32_t *tile_csr, int n_tiles, WbDet *det,
-                                 uint32_t *det_count, uint32_t shard_capacity, uint32_t *tile_hist,
-                                 uint32_t *alive) {
-    WB_REQUIRE(model && chn && levels && tiles && tile_csr && det_count, "wb_cascade_launch: null pointer");
-    WB_REQUIRE(tile_hist || model->n_stages == 0, "wb_cascade_launch: tile_hist scratch is null");
+                                 const WbTile *tiles, int n_tiles, WbDet *det, uint32_t *det_count,
+                                 uint32_t shard_capacity, uint32_t *alive) {
+    WB_REQUIRE(model && chn && levels && tiles && det_count, "wb_cascade_launch: null pointer");
     WB_REQUIRE(det || shard_capacity == 0, "wb_cascade_launch: det is null but capacity > 0");
     WB_REQUIRE(batch >= 1 && batch <= 65535, "wb_cascade_launch: batch %d out of range", batch);
     WB_REQUIRE(n_levels >= 1 && n_tiles >= 1, "wb_cascade_launch: empty launch");
@@ -923,8 +896,6 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
     a.det_count = det_count;
     a.det_cap = shard_capacity;
     a.alive = alive;
-    a.tile_hist = tile_hist;
-    a.tile_csr = tile_csr;
     a.n_tiles = n_tiles;
     static const int dbg = getenv("WB_CASC_DBG") ? atoi(getenv("WB_CASC_DBG")) : 0;
     a.dbg = dbg;
@@ -947,13 +918,10 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
         g.T = model->n_stages; g.m = model->m; g.n = model->n; g.C = model->C;
         g.node_off = model->g_node_off; g.feat = model->g_feat; g.left = model->g_left; g.right = model->g_right;
         g.thr = model->g_thr; g.pred = model->g_pred; g.theta = model->g_theta;
-        g.det = det; g.det_count = det_count; g.det_cap = shard_capacity; g.tile_hist = tile_hist;
+        g.det = det; g.det_count = det_count; g.det_cap = shard_capacity; g.alive = alive;
         size_t lds = (((size_t)g.T * 4 + 15) & ~(size_t)15) + 256 * 8;
         WB_REQUIRE(lds <= 64 * 1024, "wb_cascade_launch: %d stages exceed the generic kernel's LDS", g.T);
         hipLaunchKernelGGL(cascade_generic_kernel, grid, dim3(256), lds, st, g);
-        if (g.T > 0 && alive)
-            hipLaunchKernelGGL(alive_reduce_kernel, dim3(n_levels, grid.y), dim3(1024), 0, st, tile_hist, tile_csr,
-                               n_levels, n_tiles, g.T, alive);
         WB_HIP_CHECK(hipGetLastError());
         return WB_OK;
     }

@@ -9,7 +9,8 @@
 // with two atomics per octave.
 //
 // minmax encoding: mm[0] = max over ~key(pixel)  (so min key = ~mm[0]),  mm[1] = max over key;
-// both are plain atomicMax on a zero-initialised word, so the buffer is reset with one memset.
+// both are plain atomicMax on a word the CALLER has zeroed (like the cascade's counters: one memset of one
+// control block per step can then serve every kernel of the step).
 #include "wb_common.h"
 
 namespace {
@@ -348,7 +349,6 @@ int launch_octaves_f64(hipStream_t st, const double *img, int dtype, int batch, 
         case WB_DTYPE_I32: bits = 32; sgn = 1; break;
         case WB_DTYPE_U32: bits = 32; break;
     }
-    WB_HIP_CHECK(hipMemsetAsync(minmax, 0, sizeof(unsigned long long) * 2 * (size_t)batch * n_oct, st));
     const int64_t n0 = (int64_t)H * W;
     int blocks = (int)((n0 + 255) / 256);
     blocks = blocks > 2048 ? 2048 : blocks;
@@ -380,7 +380,6 @@ int launch_octaves(hipStream_t st, const T *img, int batch, int H, int W, int64_
         w >>= 1;
     }
     constexpr int OB = Blk<T>::OB, OB_LEVELS = Blk<T>::LEVELS;
-    WB_HIP_CHECK(hipMemsetAsync(minmax, 0, sizeof(uint32_t) * 2 * (size_t)batch * n_oct, st));
     const int bx = (W + OB - 1) / OB, by = (H + OB - 1) / OB;
     hipLaunchKernelGGL(octaves_block_kernel<T>, dim3(bx * by, batch), dim3(256), 0, st, img, img_stride, oct, oct_stride,
                        d, n_oct, bx, minmax);

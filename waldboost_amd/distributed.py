@@ -25,48 +25,51 @@ def shard_range(n_items, rank, world):
 
 
 class DetectionGatherer:
-    """All-gathers every rank's sharded detection buffer (engine.DetBuffer.buf: counters in the
-    first rows, WbDet records after) -- one fixed-size collective, no host read-back of counts."""
+    """The sync-free gather bench.py overlaps with the next step: every rank's PACKED detections (a 4-word header
+    + the valid records back to back, wb_det_pack_launch / PyramidEngine.pack) are all-gathered as a fixed-size
+    prefix of `rows` records -- sized once from what the workload produces, not from the buffer's capacity -- with
+    no host read-back of counts.  `merged` tells from the headers whether a prefix was too short."""
 
-    def __init__(self, detb, group=None):
+    def __init__(self, rows, device, group=None):
         import torch
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.NS, self.cap = detb.NS, detb.cap
-        self.rows = detb.buf.shape[0]
-        self.recv = torch.zeros((self.world * self.rows, 4), dtype=torch.int32, device=detb.buf.device)
+        self.rows = int(rows)                                     # records per rank in the collective (+ 1 header row)
+        self.recv = torch.zeros((self.world * (1 + self.rows), 4), dtype=torch.int32, device=device)
         # gloo has no all_gather for device tensors: a rehearsal of the multi-rank loop on one GPU
         # (bench.py --backend gloo) stages through the host; the real path is RCCL ("nccl")
-        self._host_staged = detb.buf.is_cuda and dist.get_backend(group) == "gloo"
+        self._host_staged = torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
 
-    def gather(self, detb, async_op=False):
+    def gather(self, packed, async_op=False):
+        """packed: int32 [>= 1 + rows, 4] as wb_det_pack_launch writes it."""
+        send = packed[: 1 + self.rows]
         if self._host_staged:
             import torch
             recv = torch.empty(self.recv.shape, dtype=torch.int32)
-            self.dist.all_gather_into_tensor(recv, detb.buf.cpu(), group=self.group)
+            self.dist.all_gather_into_tensor(recv, send.cpu(), group=self.group)
             self.recv.copy_(recv)
             return None
-        return self.dist.all_gather_into_tensor(self.recv, detb.buf, group=self.group, async_op=async_op)
+        return self.dist.all_gather_into_tensor(self.recv, send, group=self.group, async_op=async_op)
 
     def merged(self, images_per_rank):
         """Host-side merge on any rank: records of all ranks with image indices made global
-        (rank r's local image i -> sum(images_per_rank[:r]) + i), in reference order.  Raises if
-        a shard overflowed."""
+        (rank r's local image i -> sum(images_per_rank[:r]) + i), in reference order.  Raises if a rank's
+        detection buffer overflowed or its detections did not fit the gathered prefix."""
         from ._native import DET_DTYPE
-        recv = self.recv.cpu().numpy().reshape(self.world, self.rows, 4)
+        recv = self.recv.cpu().numpy().reshape(self.world, 1 + self.rows, 4)
         parts, base = [], 0
         for r in range(self.world):
-            counts = recv[r, : self.NS // 4].reshape(-1).view(np.uint32)
-            if counts.max(initial=0) > self.cap:
-                raise OverflowError(f"rank {r}: a detection shard holds {counts.max()} records, capacity {self.cap}")
-            recs = recv[r, self.NS // 4:].reshape(self.NS, self.cap, 4)
-            for s in range(self.NS):
-                d = recs[s, : counts[s]].copy().view(DET_DTYPE).reshape(-1)
-                d["image"] += base
-                parts.append(d)
+            total, worst, present, cap = (int(x) for x in recv[r, 0])
+            if worst > cap:
+                raise OverflowError(f"rank {r}: a detection shard holds {worst} records, capacity {cap}")
+            if total > self.rows:
+                raise OverflowError(f"rank {r}: {total} detections, the gathered prefix holds {self.rows}")
+            d = recv[r, 1: 1 + total].copy().view(DET_DTYPE).reshape(-1)
+            d["image"] += base
+            parts.append(d)
             base += int(images_per_rank[r])
         out = np.concatenate(parts) if parts else np.zeros(0, DET_DTYPE)
         order = np.lexsort((out["c"], out["r"], out["level"], out["image"]))

@@ -121,18 +121,16 @@ class DeviceCascade:
 
 
 class DetBuffer:
-    """Sharded append buffer of WbDet records (include/waldboost_hip.h: WB_DET_SHARDS regions of
-    `cap` records, one counter each).  One contiguous int32 [NS/4 + NS*cap, 4] block: the first
-    NS/4 rows are the NS counters, the records follow -- so the whole thing can be handed to a
-    collective as is."""
+    """Sharded append buffer of WbDet records (include/waldboost_hip.h: WB_DET_SHARDS regions of `cap` records,
+    one counter each).  `counts` may be a view the caller provides -- PyramidEngine keeps the counters in its
+    control block, so that ONE memset per step resets them together with the other accumulators."""
 
-    def __init__(self, cap, dev):
+    def __init__(self, cap, dev, counts=None):
         import torch
         self.NS = nat.WB_DET_SHARDS
         self.cap = int(cap)
-        self.buf = torch.zeros((self.NS // 4 + self.NS * self.cap, 4), dtype=torch.int32, device=dev)
-        self.counts = self.buf[: self.NS // 4].view(-1)
-        self.recs = self.buf[self.NS // 4:]
+        self.counts = counts if counts is not None else torch.zeros(self.NS, dtype=torch.int32, device=dev)
+        self.recs = torch.zeros((self.NS * self.cap, 4), dtype=torch.int32, device=dev)
 
     def zero(self):
         self.counts.zero_()
@@ -152,7 +150,7 @@ class DetBuffer:
     def compact(self):
         """All valid records as one int32 [n, 4] tensor (shard order)."""
         import torch
-        ar = torch.arange(self.cap, device=self.buf.device, dtype=torch.int32)
+        ar = torch.arange(self.cap, device=self.recs.device, dtype=torch.int32)
         mask = ar[None, :] < self.counts[:, None].clamp(max=self.cap)
         return self.recs.view(self.NS, self.cap, 4)[mask]
 
@@ -198,8 +196,12 @@ class PyramidEngine:
         self.img = self._img_flat[: self.batch * p.H * p.W].view(self.batch, p.H, p.W)
         self._oct_flat = torch.zeros(self.batch * p.oct_total + 16, dtype=self.tdtype, device=dev)
         self.oct = self._oct_flat[: self.batch * p.oct_total].view(self.batch, p.oct_total)
-        self.minmax = torch.zeros((self.batch, max(p.n_oct, 1), 2), dtype=torch.int64 if self.wide_keys else torch.int32,
-                                  device=dev)
+        # control block: [per-octave (min, max) keys | detection shard counters | alive[B, L, T]] -- everything the
+        # kernels of one step ACCUMULATE into, contiguous, so that one memset at the start of a step resets it all
+        # (three separate fills and the statistics reduction used to be four extra launches per image)
+        self._mm_words = self.batch * max(p.n_oct, 1) * 2 * (2 if self.wide_keys else 1)
+        self._alive_words = 0
+        self._alloc_ctrl(0)
         table, total = p.level_table()
         self.chn_stride = int(total)
         self.level_np = table
@@ -220,8 +222,6 @@ class PyramidEngine:
         self.det_capacity = int(det_capacity)
         self._h_packed = self._h_alive = self._fetch_ev = None
         self._alloc_det()
-        self.alive = None
-        self._casc = {}
         if exact_single:
             # a channel function on a bare image: no resize happens, so the clip range is (-inf, +inf)
             if self.wb_dtype == nat.WB_DTYPE_U8:
@@ -233,13 +233,44 @@ class PyramidEngine:
             self.minmax[:, :, 0] = int(np.array([~np.uint32(lo)], np.uint32).view(np.int32)[0])   # word 0 stores max(~key), see csrc/wb_octaves.hip
             self.minmax[:, :, 1] = int(np.array([hi], np.uint32).view(np.int32)[0])
 
+    def _alloc_ctrl(self, alive_words):
+        """(Re)allocate the control block with room for `alive_words` statistics words; the views into it follow."""
+        import torch
+        old = getattr(self, "ctrl", None)
+        NS = nat.WB_DET_SHARDS
+        self._alive_words = int(alive_words)
+        self.ctrl = torch.zeros(self._mm_words + NS + max(self._alive_words, 1), dtype=torch.int32, device=self.dev)
+        mm = self.ctrl[: self._mm_words]
+        if old is not None:
+            mm.copy_(old[: self._mm_words])            # (exact_single keeps a preset clip range there)
+        self.minmax = (mm.view(torch.int64) if self.wide_keys else mm).view(self.batch, -1, 2)
+        self._counts = self.ctrl[self._mm_words: self._mm_words + NS]
+        if getattr(self, "detb", None) is not None:
+            self.detb.counts = self._counts
+        self._casc = {}
+
+    def _alive_view(self, T1):
+        L = max(self.plan.n_levels, 1)
+        need = self.batch * L * T1
+        if need > self._alive_words:
+            self._alloc_ctrl(need)
+        o = self._mm_words + nat.WB_DET_SHARDS
+        return self.ctrl[o: o + need].view(self.batch, L, T1)
+
+    def reset_step(self, stt=None, octaves=True):
+        """ONE memset: the accumulators the coming launches add into -- the octaves' (min, max) keys (unless they
+        are preset / not recomputed), the detection counters and, with a cascade state, its alive[B, L, T]."""
+        lo = 0 if (octaves and not self.exact_single) else self._mm_words
+        hi = self._mm_words + (nat.WB_DET_SHARDS + stt["alive"].numel() if stt is not None else 0)
+        if hi > lo:
+            self.ctrl[lo:hi].zero_()
+
     def _alloc_det(self):
         """Sharded detection buffer; det_capacity is the total record capacity, split evenly over
         the shards."""
         cap = max(16, -(-self.det_capacity // nat.WB_DET_SHARDS))
         self.det_capacity = cap * nat.WB_DET_SHARDS
-        self.detb = DetBuffer(cap, self.dev)
-        self.det_buf = self.detb.buf
+        self.detb = DetBuffer(cap, self.dev, counts=self._counts)
         self.packed = None            # header + all valid records back to back (wb_det_pack_launch), allocated on first use
 
     # ------------------------------------------------------------------ input
@@ -328,9 +359,6 @@ class PyramidEngine:
                                               nat.ptr(self.chn), self.chn_stride, None, None, 0),
                   "wb_channels_launch")
 
-    def run_channels(self, rank_dm=None, floats=True):
-        self.launch_octaves()
-        self.launch_channels(rank_dm, floats)
 
     def _casc_state(self, dm):
         import torch
@@ -338,21 +366,18 @@ class PyramidEngine:
         stt = self._casc.get(key)
         if stt is None:
             tiles = self.plan.casc_tiles(dm.m, dm.n, dm.tile_rows, dm.tile_cols)
-            csr = self.plan.tile_csr(tiles, max(self.plan.n_levels, 1))
             T1 = max(dm.n_stages, 1)
+            alive = self._alive_view(T1)                # (may re-allocate the control block and drop other states)
             stt = dict(
                 dm=dm, n_tiles=int(tiles.size),
                 tiles=torch.from_numpy(tiles.view(np.uint8).copy()).to(self.dev) if tiles.size else None,
-                csr=torch.from_numpy(csr).to(self.dev),
-                tile_hist=torch.empty((self.batch, max(int(tiles.size), 1), T1), dtype=torch.int32, device=self.dev),
-                alive=torch.zeros((self.batch, max(self.plan.n_levels, 1), T1), dtype=torch.int32, device=self.dev))
+                alive=alive)
             self._casc = {key: stt}          # one cascade resident per engine
         return stt
 
-    def launch_cascade(self, dm, reduce=True, ranks=False):
-        """The cascade scan; reduce=False launches the tile kernel alone (no per-level statistics), which
-        is what bench.py times for the roofline of that kernel.  ranks=True scans self.rank (written for `dm` by
-        launch_channels) instead of the channel buffer."""
+    def launch_cascade(self, dm, ranks=False, stats=True):
+        """The cascade scan, adding into the detection counters and (stats) alive[B, L, T] -- reset_step first.
+        ranks=True scans self.rank (written for `dm` by launch_channels) instead of the channel buffer."""
         stt = self._casc_state(dm)
         if stt["n_tiles"] == 0:
             return stt
@@ -362,27 +387,35 @@ class PyramidEngine:
                                              nat.WB_DTYPE_RANK8 if ranks else self.spec.wb_dtype,
                                              self.chn_stride,
                                              self.batch, nat.ptr(self.levels), self.plan.n_levels,
-                                             nat.ptr(stt["tiles"]), nat.ptr(stt["csr"]), stt["n_tiles"],
+                                             nat.ptr(stt["tiles"]), stt["n_tiles"],
                                              nat.ptr(self.detb.recs), nat.ptr(self.detb.counts), self.detb.cap,
-                                             nat.ptr(stt["tile_hist"]), nat.ptr(stt["alive"] if reduce else None)),
+                                             nat.ptr(stt["alive"] if stats else None)),
                   "wb_cascade_launch")
         return stt
 
     def run_cascade(self, dm, ranks=False):
-        """Zero the counters and scan every level of every image with cascade `dm`."""
+        """Reset the counters and statistics, then scan every level of every image with cascade `dm`."""
         stt = self._casc_state(dm)
-        self.detb.zero()
-        if stt["n_tiles"] == 0:
-            stt["alive"].zero_()
+        self.reset_step(stt, octaves=False)
         stt["ranks"] = ranks                       # (a re-scan after a buffer overflow repeats the same form)
         return self.launch_cascade(dm, ranks=ranks)
 
+    def run_channels(self, rank_dm=None, floats=True):
+        """Octaves and the channel pyramid of the resident images (no cascade)."""
+        self.reset_step(None, octaves=True)
+        self.launch_octaves()
+        self.launch_channels(rank_dm, floats)
+
     def run(self, dm):
-        """octaves -> channels -> cascade for one model: the detection path (reference model.py:149-179).  When
-        the cascade has rank tables the channels go to HBM as ranks only."""
+        """octaves -> channels -> cascade for one model: the detection path (reference model.py:149-179): one
+        memset and three kernels.  When the cascade has rank tables the channels go to HBM as ranks only."""
         fused = self.ranks_for(dm)
-        self.run_channels(dm if fused else None, floats=not fused)
-        return self.run_cascade(dm, ranks=fused)
+        stt = self._casc_state(dm)
+        self.reset_step(stt, octaves=True)
+        self.launch_octaves()
+        self.launch_channels(dm if fused else None, floats=not fused)
+        stt["ranks"] = fused
+        return self.launch_cascade(dm, ranks=fused)
 
     # ------------------------------------------------------------------ hipGraph
     def capture(self, dm):
@@ -424,6 +457,17 @@ class PyramidEngine:
             self._alloc_det()
             self.run_cascade(dm, ranks=self._casc_state(dm).get("ranks", False))
 
+    def pack(self):
+        """Pack the valid records of all shards behind a 4-word header (wb_det_pack_launch) into self.packed --
+        the form a collective or a host read-back takes; no synchronisation."""
+        import torch
+        if self.packed is None:
+            self.packed = torch.empty((1 + self.detb.NS * self.detb.cap, 4), dtype=torch.int32, device=self.dev)
+        nat.check(self.lib.wb_det_pack_launch(nat.stream_ptr(), nat.ptr(self.detb.recs), nat.ptr(self.detb.counts),
+                                              self.detb.cap, nat.ptr(self.packed), self.packed.shape[0] - 1),
+                  "wb_det_pack_launch")
+        return self.packed
+
     def fetch(self, dm, stt):
         """Everything the host needs from the last scan in ONE synchronisation: the shard contents packed on
         the device (wb_det_pack_launch), then asynchronous copies of the header + first records and of
@@ -433,16 +477,12 @@ class PyramidEngine:
         import torch
         T = dm.n_stages
         while True:
-            if self.packed is None:
-                self.packed = torch.empty((1 + self.detb.NS * self.detb.cap, 4), dtype=torch.int32, device=self.dev)
             if self._h_packed is None:
                 self._h_packed = torch.empty((1 + self._FETCH_ROWS, 4), dtype=torch.int32).pin_memory()
                 self._fetch_ev = torch.cuda.Event()
             if self._h_alive is None or self._h_alive.shape != stt["alive"].shape:
                 self._h_alive = torch.empty(stt["alive"].shape, dtype=torch.int32).pin_memory()
-            nat.check(self.lib.wb_det_pack_launch(nat.stream_ptr(), nat.ptr(self.detb.recs), nat.ptr(self.detb.counts),
-                                                  self.detb.cap, nat.ptr(self.packed), self.packed.shape[0] - 1),
-                      "wb_det_pack_launch")
+            self.pack()
             rows = min(self._h_packed.shape[0], self.packed.shape[0])
             self._h_packed[:rows].copy_(self.packed[:rows], non_blocking=True)
             self._h_alive.copy_(stt["alive"], non_blocking=True)

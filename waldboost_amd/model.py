@@ -162,19 +162,22 @@ class Model:
                         r=np.empty(0, np.int64), c=np.empty(0, np.int64), alive=np.zeros((0, T), np.int64),
                         scales=[])
         eng.load_images(image)
-        fused = eng.ranks_for(dm)                        # channels straight to threshold ranks of this cascade
-        eng.run_channels(dm if fused else None, floats=not fused)
-        return self.scan_engine(eng, ranks=fused, dm=dm)
+        stt = eng.run(dm)            # one memset + octaves + channels (straight to this cascade's threshold ranks
+        return self._collect(eng, dm, stt)                         # when it has rank tables) + cascade
 
-    def scan_engine(self, eng, ranks=False, dm=None):
+    def scan_engine(self, eng):
         """Run this cascade over the channel pyramid already resident in `eng` (channels computed
         by the caller: several models can share one pyramid, reference __init__.py:120-124).
         Returns the same dict as detect_raw and updates n_loc / n_weak."""
         m, n, Cc = self.shape
         assert Cc == eng.spec.n_channels, f"Invalid number of channels. Expected {Cc} given {eng.spec.n_channels}."
-        dm = dm if dm is not None else self.device_cascade()
+        dm = self.device_cascade()
+        return self._collect(eng, dm, eng.run_cascade(dm))
+
+    def _collect(self, eng, dm, stt):
+        """Results of the scan `stt` of image 0 of `eng`: the dict detect_raw returns; updates n_loc / n_weak."""
+        m, n, Cc = self.shape
         T = len(self)
-        stt = eng.run_cascade(dm, ranks=ranks)
         recs, alive = eng.fetch(dm, stt)                  # ONE host synchronisation: packed records + statistics
         alive = alive[0].reshape(eng.plan.n_levels, T)
         n_det = recs.shape[0]
@@ -358,19 +361,17 @@ class _SingleLevel:
         T = dm.n_stages
         if key not in self._tiles:
             tl = PyramidPlan._tiles([(max(self.u - dm.m, 0), max(self.v - dm.n, 0))], dm.tile_rows, dm.tile_cols)
-            csr = PyramidPlan.tile_csr(tl, 1)
-            self._tiles = {key: (int(tl.size), torch.from_numpy(tl.view(np.uint8).copy()).to(self.dev) if tl.size else None,
-                                 torch.from_numpy(csr).to(self.dev),
-                                 torch.empty((max(int(tl.size), 1), max(T, 1)), dtype=torch.int32, device=self.dev))}
-        n_tiles, tiles, csr, tile_hist = self._tiles[key]
-        alive = torch.zeros((1, 1, max(T, 1)), dtype=torch.int32, device=self.dev)
+            self._tiles = {key: (int(tl.size), torch.from_numpy(tl.view(np.uint8).copy()).to(self.dev) if tl.size else None)}
+        n_tiles, tiles = self._tiles[key]
+        alive = torch.empty((1, 1, max(T, 1)), dtype=torch.int32, device=self.dev)
         while True:
             self.detb.zero()
+            alive.zero_()
             if n_tiles:
                 nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.X), self.wb_dtype, 0,
-                                                     1, nat.ptr(self.levels), 1, nat.ptr(tiles), nat.ptr(csr), n_tiles,
+                                                     1, nat.ptr(self.levels), 1, nat.ptr(tiles), n_tiles,
                                                      nat.ptr(self.detb.recs), nat.ptr(self.detb.counts), self.detb.cap,
-                                                     nat.ptr(tile_hist), nat.ptr(alive)), "wb_cascade_launch")
+                                                     nat.ptr(alive)), "wb_cascade_launch")
             need = self.detb.max_count()
             if need <= self.detb.cap:
                 break
