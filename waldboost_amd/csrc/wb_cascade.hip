@@ -166,7 +166,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
     constexpr int G = GroupSize<D>::G;
     constexpr int S0 = 8;                                  // stages in phase A (multiple of G; 4 and 12 measured slower)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (values that are the same in every lane of a wave but derived from threadIdx or read from LDS are passed
+    // through readfirstlane: the compiler then keeps them -- and every count, bound and branch computed from them --
+    // in scalar registers; left as "per-lane" values they turned the queue loops below into vector code with
+    // exec-mask branches: 471 of a wave's 1251 vector instructions were in the segments, as many as in phase A)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const WbTile tile_d = a.tiles[blockIdx.x];
     const WbLevel L = a.levels[tile_d.level];
     const int b = blockIdx.y;
@@ -355,6 +359,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
             if (w < wave) before += c;
             total += c;
         }
+        total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
+        before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
         pooled = total <= 64u * WAVES;                            // same decision in every wave
     }
     {
@@ -393,6 +399,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
             }
         }
     }
+    n_q = __builtin_amdgcn_readfirstlane(n_q);
     WB_STAMP(2);
     WB_STAMP(3);
 
@@ -464,6 +471,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
                 if (w < wave) before2 += c;
                 total2 += c;
             }
+            total2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)total2);
+            before2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)before2);
             const uint32_t room = 64u * WAVES * (RPW - 1);             // queue entries behind the pooled chunks
             if (total2 <= ((uint32_t)a.spar_wg < room ? (uint32_t)a.spar_wg : room)) {   // same decision in every wave
                 uint2 *list2 = wgq + 64 * WAVES;                      // (the pooled chunks occupy the first 64 * WAVES entries)
@@ -508,7 +517,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
         uint32_t entered_t = 0;                                  // windows that entered stage rs + lane in this pass
         for (int i = 0; i < n_q; ++i) {
             const uint2 e = queue[i * qs];                       // same entry in every lane
-            const int pos = (int)e.x;
+            const int pos = __builtin_amdgcn_readfirstlane((int)e.x);
             const int wbase = ((pos >> 6) * pitch + (pos & 63)) * px_stride;
             const float p = st.template eval<U8>(tile, wbase);
             // Replay in stage order: lane k accumulates p_0 .. p_k one after the other -- the same
@@ -578,6 +587,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
     if (n_q > 0) {
         uint32_t o = wg_base;
         for (int w = 0; w < wave; ++w) o += wcnt[w];
+        o = (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
         WbDet *dst = a.det + (size_t)shard * a.det_cap;
         for (int i = lane; i < n_q; i += 64) {
             uint2 e = queue[i * qs];
@@ -622,7 +632,7 @@ __global__ __launch_bounds__(256) void cascade_generic_kernel(GenArgs a) {
     uint32_t *hist = reinterpret_cast<uint32_t *>(gsm);                       // T counters
     uint2 *list = reinterpret_cast<uint2 *>(gsm + (((size_t)a.T * 4 + 15) & ~(size_t)15));   // 256 entries
     __shared__ uint32_t n_list, base_slot;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const WbTile tile_d = a.tiles[blockIdx.x];
     const WbLevel L = a.levels[tile_d.level];
     const int b = blockIdx.y;

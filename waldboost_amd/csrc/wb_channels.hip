@@ -268,7 +268,9 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
     const Tap *__restrict__ rtap = a.taps + L.tap_off;      // row taps [nh], then column taps [nw]
     const Tap *__restrict__ ctap = rtap + L.nh;
     constexpr int NCS = RW / 64, MAINW = NCS * 64, LEFT = RW - MAINW;
-    const int lane = tid & 63, wave = tid >> 6;
+    // (readfirstlane: the wave index is the same in every lane -- said explicitly, the row loops below run on
+    // scalar counters and branches instead of vector compares and exec masks)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Levels at their octave's own size (scale 1: every level i=0 with even dims) resample with
     // weights (1, 0): t = v*1*1 + 0 + 0 + 0 = v exactly -> plain copy.
     const bool ident = (L.src_h == L.nh) && (L.src_w == L.nw);
@@ -304,7 +306,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             uint32_t *pw = reinterpret_cast<uint32_t *>(uni);
             typedef uint32_t __attribute__((aligned(1))) u32u;
             constexpr int UR = 4;
-            const int wv = tid >> 6, ln = tid & 63;
+            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
             for (int dw0 = 0; dw0 < ndw; dw0 += 64) {
                 int dw = dw0 + ln;
                 dw = dw < ndw ? dw : ndw - 1;
