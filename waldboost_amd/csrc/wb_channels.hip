@@ -71,6 +71,15 @@ __device__ inline double lane_f64(double v, int k) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// a byte from LDS through an address the compiler cannot relate to its neighbour's: two adjacent byte loads are
+// otherwise merged into ONE 16-bit load at an arbitrary (odd) address, and unaligned LDS accesses are slow on gfx950
+// (measured: -3.7 % on the whole kernel with the pairs kept apart; switching the compiler's unaligned-access mode off
+// instead would also split the patch staging's unaligned global dword loads into bytes)
+__device__ inline uint8_t lds_byte_apart(const unsigned char *p) {
+    asm volatile("" : "+v"(p));
+    return *p;
+}
+
 // scipy's order-1 resample of one output pixel: fp64, taps and additions in NI_ZoomShift's order
 __device__ inline double resample_f64(double v00, double v01, double v10, double v11, const Tap &tr, const Tap &tc) {
     double t = (v00 * tr.w0) * tc.w0;
@@ -389,13 +398,13 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
 #pragma unroll
                         for (int c = 0; c < NCS; ++c) {
                             const unsigned char *q = patch + o0[rb] + ci0[c];
-                            b[rb][c][0] = q[0]; b[rb][c][1] = q[1];
+                            b[rb][c][0] = q[0]; b[rb][c][1] = lds_byte_apart(q + 1);
                         }
                     }
 #pragma unroll
                     for (int c = 0; c < NCS; ++c) {
                         const unsigned char *q = patch + o0[rb] + ci0[c];
-                        b[rb][c][2] = q[PPITCH]; b[rb][c][3] = q[PPITCH + 1];
+                        b[rb][c][2] = q[PPITCH]; b[rb][c][3] = lds_byte_apart(q + PPITCH + 1);
                     }
                 }
                 float out[RB][NCS];
@@ -524,8 +533,8 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                 if (staged) {                        // the staged patch covers these columns too
                     const unsigned char *patch = uni;
                     const int o0 = (tr.i0 - r_lo) * PPITCH + (tc.i0 - c_lo);
-                    a00 = patch[o0]; a01 = patch[o0 + 1];
-                    a10 = patch[o0 + PPITCH]; a11 = patch[o0 + PPITCH + 1];
+                    a00 = patch[o0]; a01 = lds_byte_apart(patch + o0 + 1);
+                    a10 = patch[o0 + PPITCH]; a11 = lds_byte_apart(patch + o0 + PPITCH + 1);
                     from_lds = true;
                 }
             }
