@@ -295,15 +295,17 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
         int yl = ry0 + RH - 1; yl = yl < 0 ? 0 : (yl > L.nh - 1 ? L.nh - 1 : yl);
         int xf = rx0 < 0 ? 0 : (rx0 > L.nw - 1 ? L.nw - 1 : rx0);
         int xl = rx0 + RW - 1; xl = xl < 0 ? 0 : (xl > L.nw - 1 ? L.nw - 1 : xl);
-        const Tap t_yf = rtap[yf], t_yl = rtap[yl];
-        const Tap t_xf = ctap[xf], t_xl = ctap[xl];
-        r_lo = t_yf.i0 < t_yf.i1 ? t_yf.i0 : t_yf.i1;
-        c_lo = t_xf.i0 < t_xf.i1 ? t_xf.i0 : t_xf.i1;
-        const int r_hi = t_yl.i0 > t_yl.i1 ? t_yl.i0 : t_yl.i1;
-        const int c_hi = t_xl.i0 > t_xl.i1 ? t_xl.i0 : t_xl.i1;
+        // strict down-scale on both axes: every tap pair is (i0, i0 + 1), no mirroring (plan.axis_taps), and the
+        // patch extents follow from the first and last coordinate's i0 = floor((k + 0.5) * step - 0.5) -- the host's
+        // own fp64 expression (the tap table holds the same numbers, but loading them here put one more
+        // dependent memory round trip in front of the patch loads of every workgroup)
+        const bool strict = !ident && L.src_h > L.nh && L.src_w > L.nw;
+        auto first_tap = [](int k, double step) { return (int)floor(((double)k + 0.5) * step - 0.5); };
+        r_lo = first_tap(yf, L.sy);
+        c_lo = first_tap(xf, L.sx);
+        const int r_hi = first_tap(yl, L.sy) + 1, c_hi = first_tap(xl, L.sx) + 1;
         const int nrow = r_hi - r_lo + 1, nbyte = c_hi - c_lo + 1;
-        // strict down-scale on both axes: every tap pair is (i0, i0 + 1), no mirroring (plan.axis_taps)
-        staged = !ident && L.src_h > L.nh && L.src_w > L.nw && nrow + 1 <= PROWS && nbyte + 8 <= PPITCH;
+        staged = strict && nrow + 1 <= PROWS && nbyte + 8 <= PPITCH;
         WB_CSTAMP(1);
         if (staged) {
             // LDS row r = source row r_lo + r from column c_lo on: dword loads at byte granularity
