@@ -557,8 +557,10 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
     }
 }
 
+// (launch bound: 4 workgroups = 4 waves per SIMD is what the 39 KB of LDS admit; without it the register
+// allocator may trade that occupancy for a few more registers -- measured: 138 VGPRs, 3 waves per SIMD, +17 % time)
 template <typename T, int S, int TU, int TV, bool SMOOTH, bool FAST>
-__global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
+__global__ __launch_bounds__(256, sizeof(T) == 8 || S == 4 ? 1 : 4) void channels_kernel(ChanArgs a) {
     using G = TileGeom<S, TU, TV, SMOOTH>;
     constexpr int HS = G::HS, SU = G::SU, SV = G::SV, RH = G::RH, RW = G::RW, P = G::P;
     constexpr int PATCH_BYTES = sizeof(T) == 1 ? G::PATCH_BYTES : 0;
@@ -709,17 +711,27 @@ __global__ __launch_bounds__(256) void channels_kernel(ChanArgs a) {
             // Every value of the tile is 0 or a float32 in [2^-3, 2^11): all partial sums of the nine
             // weighted terms are multiples of 2^-26 below 2^15 -- exact in fp64 in ANY order.  So the
             // row sums are formed once, row by row, and shared by the three output rows that use them.
-            double s[3][4];
+            // Channels 0 and 2 -- |gx| and |gy| of integer gradients, pooled -- are multiples of 2^-2 (2^-4 under the
+            // shrink-4 extension) below 2^10: their nine-term sums have at most 18 significant bits and are exact in
+            // fp32 too, so these two channels need neither the conversions nor the fp64 arithmetic (the fp64 sum is the
+            // same real number, /16 is exact, and the result is representable: identical bits).
+            double s[3][2];
+            float s32[3][2];
 #pragma unroll
             for (int y = 0; y < RPT + 2; ++y) {
                 const F4 c0 = Sh[(i0 + y) * SV + j], c1 = Sh[(i0 + y) * SV + j + 1], c2 = Sh[(i0 + y) * SV + j + 2];
                 const float a0[4] = {c0.x, c0.y, c0.z, c0.w}, a1[4] = {c1.x, c1.y, c1.z, c1.w}, a2[4] = {c2.x, c2.y, c2.z, c2.w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) s[y % 3][k] = __builtin_fma(2.0, (double)a1[k], (double)a0[k]) + (double)a2[k];
+                for (int h = 0; h < 2; ++h) {
+                    s32[y % 3][h] = __builtin_fmaf(2.0f, a1[2 * h], a0[2 * h]) + a2[2 * h];
+                    s[y % 3][h] = __builtin_fma(2.0, (double)a1[2 * h + 1], (double)a0[2 * h + 1]) + (double)a2[2 * h + 1];
+                }
                 if (y >= 2) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        o[y - 2][k] = (float)((__builtin_fma(2.0, s[(y - 1) % 3][k], s[(y - 2) % 3][k]) + s[y % 3][k]) * 0.0625);
+                    for (int h = 0; h < 2; ++h) {
+                        o[y - 2][2 * h] = (__builtin_fmaf(2.0f, s32[(y - 1) % 3][h], s32[(y - 2) % 3][h]) + s32[y % 3][h]) * 0.0625f;
+                        o[y - 2][2 * h + 1] = (float)((__builtin_fma(2.0, s[(y - 1) % 3][h], s[(y - 2) % 3][h]) + s[y % 3][h]) * 0.0625);
+                    }
                 }
             }
         } else {
