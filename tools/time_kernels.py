@@ -24,4 +24,8 @@ def t(fn, it=20):
         b.record(); torch.cuda.synchronize()
         best.append(a.elapsed_time(b) / it)
     return min(best)
-print(f"{os.path.basename(os.environ.get('WB_NATIVE_LIB', 'default')):12s} B={B} channels {t(e.launch_channels):.4f} ms  cascade {t(lambda: e.run_cascade(dm)):.4f} ms")
+fused = e.ranks_for(dm)
+us = lambda ms: ms * 1e3 / B
+print(f"{os.path.basename(os.environ.get('WB_NATIVE_LIB', 'default')):12s} B={B} per image: channels(float32) {us(t(e.launch_channels)):.2f} us  "
+      f"channels(ranks) {us(t(lambda: e.launch_channels(dm, floats=False))) if fused else float('nan'):.2f} us  "
+      f"cascade {us(t(lambda: e.run_cascade(dm, ranks=fused))):.2f} us")

@@ -61,6 +61,9 @@ __device__ unsigned long long g_chan_stamps[WB_CSTAMP_WGS * WB_CSTAMP_SLOTS];
 #define WB_CSTAMP(k) do {} while (0)
 #endif
 
+#ifndef WB_CHAN_UR
+#define WB_CHAN_UR 8
+#endif
 typedef WbTap Tap;   // one axis of the bilinear resample (scipy NI_ZoomShift, order 1), host-built table
 
 // a double held by lane `k` (wave-uniform k), to every lane
@@ -74,10 +77,14 @@ __device__ inline double lane_f64(double v, int k) {
 // a byte from LDS through an address the compiler cannot relate to its neighbour's: two adjacent byte loads are
 // otherwise merged into ONE 16-bit load at an arbitrary (odd) address, and unaligned LDS accesses are slow on gfx950
 // (measured: -3.7 % on the whole kernel with the pairs kept apart; switching the compiler's unaligned-access mode off
-// instead would also split the patch staging's unaligned global dword loads into bytes)
+// instead would also split the patch staging's unaligned global dword loads into bytes).  The pointer stays an LDS
+// (address space 3) pointer through the barrier: a generic one made every such load a flat_load with 64-bit address
+// arithmetic in front of it.
+typedef const __attribute__((address_space(3))) unsigned char *LdsBytePtr;
 __device__ inline uint8_t lds_byte_apart(const unsigned char *p) {
-    asm volatile("" : "+v"(p));
-    return *p;
+    LdsBytePtr q = (LdsBytePtr)p;
+    asm volatile("" : "+v"(q));
+    return *q;
 }
 
 // scipy's order-1 resample of one output pixel: fp64, taps and additions in NI_ZoomShift's order
@@ -236,12 +243,18 @@ __device__ inline void project_int(float gx, float gy, const ChanArgs &a, float 
 // that channel: fp32 absorbs anything below 3.5e-13 into a value >= 0.7071, in any position of
 // ((a+b)+c)+d.  So the shrink is first formed from these values, and only a block whose pooled value
 // comes out 0 although it contains a gradient is redone with project_int (channels_kernel, step 2).
-__device__ inline void project_ordinary(float gx, float gy, const ChanArgs &a, float *out) {
-    const float d1 = fabsf(gx - gy), d3 = fabsf(gx + gy);
+// The FAST path runs with the canonical constants only (wb_channels_launch checks), so sin(pi/4) as a two-float split is
+// a compile-time constant: literal operands.  (Kernel arguments live in scalar registers, and an fp32 multiply / fmac
+// with a scalar-register operand issues in 4 cycles instead of 2 on gfx950 -- tools/valu_class_probe.hip.)  The split
+// product is odd in d, so it is formed from the signed difference and the |.| is left to the consumer's source modifier.
+constexpr float kSinHi = 0x1.6a09e6p-1f;
+constexpr float kSinLo = (float)(0x1.6a09e667f3bccp-1 - (double)kSinHi);
+__device__ inline void project_ordinary(float gx, float gy, const ChanArgs &, float *out) {
+    const float d1 = gx - gy, d3 = gx + gy;
     out[0] = fabsf(gx);
-    out[1] = __builtin_fmaf(d1, a.chi, d1 * a.clo);
+    out[1] = fabsf(__builtin_fmaf(d1, kSinHi, d1 * kSinLo));
     out[2] = fabsf(gy);
-    out[3] = __builtin_fmaf(d3, a.chi, d3 * a.clo);
+    out[3] = fabsf(__builtin_fmaf(d3, kSinHi, d3 * kSinLo));
 }
 
 // Tile geometry shared by the channel kernels: TU x TV outputs per workgroup, shrink S
@@ -272,7 +285,7 @@ template <int S_, int TU_, int TV_, bool SMOOTH_> struct TileGeom {
 template <typename T, typename G>
 __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &L, const T *src, const double mn,
                                               const double mx, const int ry0, const int rx0, float *R,
-                                              unsigned char *uni, const int tid) {
+                                              unsigned char *uni, float4 *rowtab, const int tid) {
     constexpr int RH = G::RH, RW = G::RW, PROWS = G::PROWS, PPITCH = G::PPITCH;
     const Tap *__restrict__ rtap = a.taps + L.tap_off;      // row taps [nh], then column taps [nw]
     const Tap *__restrict__ ctap = rtap + L.nh;
@@ -290,6 +303,11 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
     // (strongly down-scaled tiny levels) and for float32 images.
     bool staged = false;
     int r_lo = 0, c_lo = 0;
+    Tap tcs[NCS], trl, tleft;
+    trl.i0 = trl.i1 = 0; trl.w0 = trl.w1 = 0.0;
+    tleft = trl;
+#pragma unroll
+    for (int c = 0; c < NCS; ++c) tcs[c] = trl;
     if constexpr (sizeof(T) == 1) {
         int yf = ry0 < 0 ? 0 : (ry0 > L.nh - 1 ? L.nh - 1 : ry0);
         int yl = ry0 + RH - 1; yl = yl < 0 ? 0 : (yl > L.nh - 1 ? L.nh - 1 : yl);
@@ -307,6 +325,23 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
         const int nrow = r_hi - r_lo + 1, nbyte = c_hi - c_lo + 1;
         staged = strict && nrow + 1 <= PROWS && nbyte + 8 <= PPITCH;
         WB_CSTAMP(1);
+        // the taps the resample below wants -- a lane's column taps, the tile's row taps (lane l: row l), the taps of the
+        // RW % 64 right-most columns -- are requested HERE, in front of the patch loads: behind the staging barrier each
+        // of these loads was one more exposed memory round trip per workgroup
+#pragma unroll
+        for (int c = 0; c < NCS; ++c) {
+            int x = rx0 + lane + 64 * c;
+            x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
+            tcs[c] = ctap[x];
+        }
+        {
+            int ly = ry0 + (lane < RH ? lane : RH - 1);
+            ly = ly < 0 ? 0 : (ly > L.nh - 1 ? L.nh - 1 : ly);
+            trl = rtap[ly];
+            int lx = rx0 + MAINW + (lane < LEFT ? lane : 0);
+            lx = lx < 0 ? 0 : (lx > L.nw - 1 ? L.nw - 1 : lx);
+            tleft = ctap[lx];
+        }
         if (staged) {
             // LDS row r = source row r_lo + r from column c_lo on: dword loads at byte granularity
             // (global memory takes unaligned dwords), aligned LDS stores
@@ -316,7 +351,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             const int ndw = (nbyte + 1 + 3) / 4;                  // + the (i0 + 1) neighbour of the last column
             uint32_t *pw = reinterpret_cast<uint32_t *>(uni);
             typedef uint32_t __attribute__((aligned(1))) u32u;
-            constexpr int UR = 4;
+            constexpr int UR = WB_CHAN_UR;
             const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
             for (int dw0 = 0; dw0 < ndw; dw0 += 64) {
                 int dw = dw0 + ln;
@@ -334,6 +369,13 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                     for (int k = 0; k < UR; ++k) pw[rr[k] * DWP + dw] = v[k];   // duplicates rewrite the same value
                 }
             }
+            // the row taps of the tile, one entry per tile row: {patch byte offset of the upper tap row, fp32 weights}.
+            // Read back below with one wave-uniform (broadcast) LDS load per row: the values arrive in VECTOR registers
+            // -- on gfx950 an fp32 add / multiply / fmac whose operands are all vector registers issues in 2 cycles,
+            // with a scalar-register operand in 4 (tools/valu_class_probe.hip), and a v_readlane costs 4 as well
+            if (tid < RH) rowtab[tid] = make_float4(__int_as_float((trl.i0 - r_lo) * PPITCH), (float)trl.w0, (float)trl.w1, 0.0f);
+            if (LEFT > 0 && tid >= 64 && tid < 64 + LEFT)
+                rowtab[RH + tid - 64] = make_float4(__int_as_float(tleft.i0 - c_lo), (float)tleft.w0, (float)tleft.w1, 0.0f);
             __syncthreads();
         }
     }
@@ -343,30 +385,21 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             const unsigned char *patch = uni;
             int ci0[NCS];
             float wc0f[NCS], wc1f[NCS];
-            Tap tc[NCS];
+            const Tap (&tc)[NCS] = tcs;
 #pragma unroll
             for (int c = 0; c < NCS; ++c) {
-                int x = rx0 + lane + 64 * c;
-                x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
-                tc[c] = ctap[x];
                 ci0[c] = tc[c].i0 - c_lo;
                 wc0f[c] = (float)tc[c].w0;
                 wc1f[c] = (float)tc[c].w1;
             }
-            // row taps: lane l holds those of tile row l (RH <= 64); a row's values reach the scalar
-            // registers by readlane, so the row loop has no memory access besides LDS
+            // (fp64 row taps for the exact redo: lane l holds those of tile row l -- trl -- fetched by readlane there)
             static_assert(RH <= 64, "one lane per tile row");
-            int ly = ry0 + (lane < RH ? lane : RH - 1);
-            ly = ly < 0 ? 0 : (ly > L.nh - 1 ? L.nh - 1 : ly);
-            const Tap trl = rtap[ly];
-            const int l_o0 = (trl.i0 - r_lo) * PPITCH;
-            const float l_wr0 = (float)trl.w0, l_wr1 = (float)trl.w1;
             // Each wave owns a strip of consecutive tile rows and walks it two rows per pass: every tap byte of
             // the pass is requested before the first is used, and the rare exact redo is deferred behind all the
-            // fast-path arithmetic (one branch per pass).  Consecutive output rows of a down-scale by less than 2
-            // usually share a source row (the lower taps of row k are the upper taps of row k + 1): its
-            // horizontal interpolation -- two conversions, a multiply and an fma per pixel -- is then taken
-            // over instead of recomputed; which rows share is wave-uniform (the row taps are scalars).
+            // fast-path arithmetic (one branch per pass; which pixels want it is kept as lane masks).  Consecutive
+            // output rows of a down-scale by less than 2 usually share a source row (the lower taps of row k are the
+            // upper taps of row k + 1): its horizontal interpolation -- two conversions, a multiply and an fma per
+            // pixel -- is then taken over instead of recomputed; which rows share is wave-uniform.
 #ifndef WB_CHAN_RB
 #define WB_CHAN_RB 2
 #endif
@@ -382,34 +415,46 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                 pb[c][0] = pb[c][1] = 0;
             }
             auto hlerp = [&](uint8_t x0, uint8_t x1, int c) { return __builtin_fmaf((float)x1, wc1f[c], (float)x0 * wc0f[c]); };
+            auto row_entry = [&](int k0, int rb) {
+                int k = k0 + rb;
+                k = k < k_hi ? k : k_hi - 1;
+                return rowtab[k];
+            };
+            float4 cur[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) cur[rb] = row_entry(k_lo, rb);
             for (int k0 = k_lo; k0 < k_hi; k0 += RB) {
                 uint8_t b[RB][NCS][4];
                 float wr0[RB], wr1[RB];
-                int o0[RB];
+                int o0[RB], o0v[RB];
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
-                    int k = k0 + rb;
-                    k = k < k_hi ? k : k_hi - 1;
-                    o0[rb] = __builtin_amdgcn_readlane(l_o0, k);
-                    wr0[rb] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l_wr0), k));
-                    wr1[rb] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l_wr1), k));
+                    o0v[rb] = __float_as_int(cur[rb].x);                       // vector copy: addresses
+                    o0[rb] = __builtin_amdgcn_readfirstlane(o0v[rb]);          // scalar copy: which rows share
+                    wr0[rb] = cur[rb].y;
+                    wr1[rb] = cur[rb].z;
                     // (a00, a01) / (a10, a11) sit at i0, i0 + 1 of two consecutive patch rows; the upper pair is
                     // not read again when it is the previous row's lower pair
                     const int o_above = rb == 0 ? o_prev : o0[rb - 1] + PPITCH;
                     if (o0[rb] != o_above) {                                    // wave-uniform
 #pragma unroll
                         for (int c = 0; c < NCS; ++c) {
-                            const unsigned char *q = patch + o0[rb] + ci0[c];
+                            const unsigned char *q = patch + (o0v[rb] + ci0[c]);
                             b[rb][c][0] = q[0]; b[rb][c][1] = lds_byte_apart(q + 1);
                         }
                     }
 #pragma unroll
                     for (int c = 0; c < NCS; ++c) {
-                        const unsigned char *q = patch + o0[rb] + ci0[c];
+                        const unsigned char *q = patch + (o0v[rb] + ci0[c]);
                         b[rb][c][2] = q[PPITCH]; b[rb][c][3] = lds_byte_apart(q + PPITCH + 1);
                     }
                 }
+                // the next pass's row entries: requested here, used after this pass's arithmetic
+                float4 nxt[RB];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) nxt[rb] = row_entry(k0 + RB, rb);
                 float out[RB][NCS];
+                bool need[RB][NCS];
                 bool redo = false;
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
@@ -429,11 +474,12 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                         bot[c] = hlerp(b[rb][c][2], b[rb][c][3], c);
                         hprev[c] = bot[c];
                         pb[c][0] = b[rb][c][2]; pb[c][1] = b[rb][c][3];
-                        redo |= !Src<T>::fast_rows(top[c], bot[c], wr0[rb], wr1[rb], out[rb][c]);
+                        need[rb][c] = !Src<T>::fast_rows(top[c], bot[c], wr0[rb], wr1[rb], out[rb][c]);
+                        redo |= need[rb][c];
                     }
                     o_prev = o0[rb] + PPITCH;
                 }
-                if (redo) {                                                // rare: exact fp64 with the full taps
+                if (__builtin_amdgcn_ballot_w64(redo) != 0) {              // rare: exact fp64 with the full taps
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) {
                         int k = k0 + rb;
@@ -446,9 +492,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                         tr.w1 = lane_f64(trl.w1, k);
 #pragma unroll
                         for (int c = 0; c < NCS; ++c) {
-                            float f;
-                            if (!Src<T>::fast((float)b[rb][c][0], (float)b[rb][c][1], (float)b[rb][c][2], (float)b[rb][c][3],
-                                              wr0[rb], wr1[rb], wc0f[c], wc1f[c], f))
+                            if (need[rb][c])
                                 out[rb][c] = Src<T>::finish(resample_f64((double)b[rb][c][0], (double)b[rb][c][1], (double)b[rb][c][2],
                                                                          (double)b[rb][c][3], tr, tc[c]), mn, mx, a.src_int);
                         }
@@ -461,6 +505,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
 #pragma unroll
                         for (int c = 0; c < NCS; ++c) R[k * RW + lane + 64 * c] = out[rb][c];
                     }
+                    cur[rb] = nxt[rb];
                 }
             }
         }
@@ -528,25 +573,29 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             int y = ry0 + k, x = rx0 + q;
             y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
             x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
-            const Tap tr = rtap[y], tc = ctap[x];
-            T a00, a01, a10, a11;
-            bool from_lds = false;
+            float out = 0.0f;
+            bool ok = false;
             if constexpr (sizeof(T) == 1) {
-                if (staged) {                        // the staged patch covers these columns too
+                if (staged) {                        // the staged patch covers these columns too; taps from the LDS tables
                     const unsigned char *patch = uni;
-                    const int o0 = (tr.i0 - r_lo) * PPITCH + (tc.i0 - c_lo);
-                    a00 = patch[o0]; a01 = lds_byte_apart(patch + o0 + 1);
-                    a10 = patch[o0 + PPITCH]; a11 = lds_byte_apart(patch + o0 + PPITCH + 1);
-                    from_lds = true;
+                    const float4 er = rowtab[k], ec = rowtab[RH + q - MAINW];
+                    const int o0 = __float_as_int(er.x) + __float_as_int(ec.x);
+                    const uint8_t a00 = patch[o0], a01 = lds_byte_apart(patch + o0 + 1);
+                    const uint8_t a10 = patch[o0 + PPITCH], a11 = lds_byte_apart(patch + o0 + PPITCH + 1);
+                    ok = Src<T>::fast((float)a00, (float)a01, (float)a10, (float)a11, er.y, er.z, ec.y, ec.z, out);
+                    if (!ok) {
+                        const Tap tr = rtap[y], tc = ctap[x];
+                        out = Src<T>::finish(resample_f64((double)a00, (double)a01, (double)a10, (double)a11, tr, tc), mn, mx, a.src_int);
+                    }
+                    R[k * RW + q] = out;
+                    continue;
                 }
             }
-            if (!from_lds) {
-                const T *r0 = src + (int64_t)tr.i0 * L.src_w;
-                const T *r1 = src + (int64_t)tr.i1 * L.src_w;
-                a00 = r0[tc.i0]; a01 = r0[tc.i1]; a10 = r1[tc.i0]; a11 = r1[tc.i1];
-            }
-            float out = 0.0f;
-            bool ok = ident;
+            const Tap tr = rtap[y], tc = ctap[x];
+            const T *r0 = src + (int64_t)tr.i0 * L.src_w;
+            const T *r1 = src + (int64_t)tr.i1 * L.src_w;
+            const T a00 = r0[tc.i0], a01 = r0[tc.i1], a10 = r1[tc.i0], a11 = r1[tc.i1];
+            ok = ident;
             if (ident) out = (float)a00;
             if constexpr (Src<T>::kFastResample)
                 if (!ok) ok = Src<T>::fast((float)a00, (float)a01, (float)a10, (float)a11, (float)tr.w0, (float)tr.w1,
@@ -569,6 +618,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 || S == 4 ? 1 : 4) void channel
     __shared__ __attribute__((aligned(16))) float R[R_FLOATS];
     __shared__ __attribute__((aligned(16))) unsigned char uni[UNI_BYTES];
     __shared__ uint32_t odd_values;      // set when a shrunk value lies outside the exact-sum range (see step 3)
+    __shared__ float4 rowtab[sizeof(T) == 1 ? RH + RW % 64 : 1];   // row taps of the tile, taps of the RW % 64 last columns (uint8 images, staged patch)
     F4 *Sh = reinterpret_cast<F4 *>(uni);
     constexpr bool SEPARABLE = SMOOTH && FAST;
     if (SEPARABLE && threadIdx.x == 0) odd_values = 0;
@@ -586,7 +636,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 || S == 4 ? 1 : 4) void channel
 
     const int ry0 = S * (u0 - HS) - 1, rx0 = S * (v0 - HS) - 1;
     WB_CSTAMP(0);
-    resample_tile<T, G>(a, L, src, mn, mx, ry0, rx0, R, uni, tid);
+    resample_tile<T, G>(a, L, src, mn, mx, ry0, rx0, R, uni, rowtab, tid);
     __syncthreads();
     WB_CSTAMP(4);
     if (a.dbg & 1) return;
@@ -824,6 +874,7 @@ __global__ __launch_bounds__(256) void channels_u1_kernel(ChanArgs a) {
     constexpr int UNI_BYTES = G::SH_BYTES > G::PATCH_BYTES ? G::SH_BYTES : G::PATCH_BYTES;
     __shared__ float R[RH * RW];
     __shared__ __attribute__((aligned(16))) unsigned char uni[UNI_BYTES];
+    __shared__ float4 rowtab[RH + RW % 64];
     uint32_t *Sh = reinterpret_cast<uint32_t *>(uni);     // packed channels of one shrunk pixel
 
     const WbTile tile = a.tiles[blockIdx.x];
@@ -836,7 +887,7 @@ __global__ __launch_bounds__(256) void channels_u1_kernel(ChanArgs a) {
     double mn, mx;
     clip_range<T>(a, b, L.oct, mn, mx);
     const int ry0 = S * (u0 - HS) - 1, rx0 = S * (v0 - HS) - 1;
-    resample_tile<T, G>(a, L, src, mn, mx, ry0, rx0, R, uni, tid);
+    resample_tile<T, G>(a, L, src, mn, mx, ry0, rx0, R, uni, rowtab, tid);
     __syncthreads();
     if (a.dbg & 1) return;
 
