@@ -32,6 +32,8 @@
  *        -> wb_boxes_launch
  *   reference waldboost/model.py:173-179 (Model.detect: per-level results concatenated for the caller)
  *        -> wb_det_pack_launch
+ *   reference waldboost/model.py:136-147 + :173-179 (get_boxes on the concatenated, ordered detections)
+ *        -> wb_det_finish_launch
  *   reference waldboost/samples.py:14-43 (gather_samples), waldboost/model.py:181-214 (Model.predict),
  *        waldboost/training.py:73-83 (DTree.apply/predict): the training-time callers of the hot path
  *        -> wb_gather_samples_launch, wb_samples_predict_launch, wb_tree_apply_launch
@@ -45,7 +47,7 @@
 extern "C" {
 #endif
 
-#define WB_ABI_VERSION 3
+#define WB_ABI_VERSION 4
 
 #define WB_OK 0
 #define WB_ERR_INVALID (-1)     /* bad argument / malformed model */
@@ -257,6 +259,21 @@ int wb_cascade_launch(void *stream, const WbModel *model, const void *chn, int c
  * (multi-GPU gather of detections); no host synchronisation. */
 int wb_det_pack_launch(void *stream, const WbDet *det, const uint32_t *det_count, uint32_t shard_capacity,
                        int32_t *packed, uint32_t packed_capacity);
+
+/* Model.detect's last step in one launch (model.py:136-147, :173-179): for the valid records of all shards, at their
+ * packed positions i < out_capacity,
+ *   out  dev, 16-byte aligned:  int32 header[4] as wb_det_pack_launch writes it
+ *                             | uint64 keys[out_capacity]   level << 54 | r << 40 | c << 26 | i
+ *                             | float  boxes[out_capacity][4]   (c, r, c + n, r + m) * inv_scale[level]
+ *                             | float  scores[out_capacity]
+ * Sorting the keys gives the reference order (level, r, c); a sorted key's low 26 bits index boxes / scores.
+ *   inv_scale  dev float32[n_levels] = float32(1 / scale) per level; m, n = window rows, cols
+ *   n_levels, max_rows, max_cols  the scan's extent, checked against the key's 10 / 14 / 14 bits
+ *   out_capacity  even, <= 2^26.   WB_ERR_UNSUPPORTED when the extent does not fit the key (use wb_det_pack_launch +
+ *   wb_boxes_launch then).  No host synchronisation. */
+int wb_det_finish_launch(void *stream, const WbDet *det, const uint32_t *det_count, uint32_t shard_capacity,
+                         const float *inv_scale, int n_levels, int max_rows, int max_cols, int m, int n,
+                         void *out, uint32_t out_capacity);
 
 /* One tree evaluated at explicit window origins (rs[i], cs[i]) of an HWC channel image
  * X[u][v][C] of x_dtype (WB_DTYPE_F32 / WB_DTYPE_U8); out[i] = prediction of the leaf reached

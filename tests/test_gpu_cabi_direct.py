@@ -138,6 +138,30 @@ def test_pyramid_and_cascade_through_the_raw_abi():
     _check(lib, lib.wb_boxes_launch(st, P(recs.data_ptr()), C.c_int64(d.size), P(inv.data_ptr()), C.c_int(12), C.c_int(12),
                                     P(boxes.data_ptr()), P(scores.data_ptr())))
     assert np.array_equal(boxes.cpu().numpy().view(np.uint32), ref["boxes"].view(np.uint32))
+    # the last step of Model.detect in one launch (wb_det_finish_launch): header | sort keys | boxes | scores
+    Pn = 2 * ((d.size + 8) // 2)
+    fin = torch.zeros(16 + 28 * Pn, dtype=torch.uint8, device=dev)
+    _check(lib, lib.wb_det_finish_launch(st, P(det2[16:].data_ptr()), P(det2.data_ptr()), C.c_uint32(cap), P(inv.data_ptr()),
+                                         C.c_int(plan.n_levels), C.c_int(max(int(lv["u"]) for lv in plan.levels)),
+                                         C.c_int(max(int(lv["v"]) for lv in plan.levels)), C.c_int(12), C.c_int(12),
+                                         P(fin.data_ptr()), C.c_uint32(Pn)))
+    torch.cuda.synchronize()
+    fh = fin.cpu().numpy()
+    assert fh[:16].view(np.int32).tolist() == [d.size, int(det2[:16].max()), d.size, cap]
+    keys = np.sort(fh[16:16 + 8 * Pn].view(np.uint64)[:d.size])
+    at = (keys & np.uint64((1 << 26) - 1)).astype(np.intp)
+    assert np.array_equal((keys >> np.uint64(54)).astype(np.int64), ref["level"])
+    assert np.array_equal(((keys >> np.uint64(40)) & np.uint64(0x3fff)).astype(np.int64), ref["r"])
+    assert np.array_equal(((keys >> np.uint64(26)) & np.uint64(0x3fff)).astype(np.int64), ref["c"])
+    fb = fh[16 + 8 * Pn:16 + 24 * Pn].view(np.float32).reshape(Pn, 4)[at]
+    fs = fh[16 + 24 * Pn:].view(np.float32)[at]
+    assert np.array_equal(fb.view(np.uint32), ref["boxes"].view(np.uint32))
+    assert np.array_equal(fs.view(np.uint32), ref["scores"].view(np.uint32))
+    # a pyramid beyond the key's bit fields is refused, not truncated
+    assert lib.wb_det_finish_launch(st, P(det2[16:].data_ptr()), P(det2.data_ptr()), C.c_uint32(cap), P(inv.data_ptr()),
+                                    C.c_int(2000), C.c_int(100), C.c_int(100), C.c_int(12), C.c_int(12), P(fin.data_ptr()),
+                                    C.c_uint32(Pn)) != 0
+    assert b"do not fit" in lib.wb_last_error()
     _check(lib, lib.wb_model_destroy(h))
     # error reporting stays on the C side of the boundary
     assert lib.wb_cascade_launch(st, None, None, 1, 0, 1, None, 1, None, 1, None, None, 0, None) != 0

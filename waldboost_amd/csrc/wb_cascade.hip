@@ -824,6 +824,52 @@ __global__ __launch_bounds__(256) void det_pack_kernel(const WbDet *det, const u
         if (before + i < out_cap) dst[before + i] = src[i];
 }
 
+// Model.detect's last step on the device (reference model.py:136-147 get_boxes, :173-179 the concatenated result):
+// for every valid record of every shard, at its packed position i < out_cap,
+//   keys[i]   = level << 54 | r << 40 | c << 26 | i     sorting these 64-bit words IS the reference order (level, r, c),
+//                                                       and the low 26 bits say where the sorted record's box and score lie
+//   boxes[i]  = (c, r, c + n, r + m) * fp32(1 / scale[level])   (boxes_kernel's arithmetic)
+//   scores[i] = score
+// behind det_pack_kernel's 4-word header, in ONE buffer: header | keys[out_cap] | boxes[out_cap] | scores[out_cap].
+// The host reads it back with one copy, sorts the keys and gathers -- no per-field arithmetic on the host.
+__global__ __launch_bounds__(256) void det_finish_kernel(const WbDet *det, const uint32_t *det_count, uint32_t cap,
+                                                          const float *inv_scale, int m, int n, int32_t *out, uint32_t out_cap) {
+    static_assert(WB_DET_SHARDS == 64, "one counter per lane of a wave");
+    const int shard = blockIdx.x, lane = threadIdx.x & 63;
+    const uint32_t raw = det_count[lane];
+    const uint32_t mine = raw < cap ? raw : cap;
+    uint32_t before = 0, total = 0, worst = 0;
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)mine, s);
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)raw, s);
+        before += s < shard ? c : 0u;
+        total += c;
+        worst = r > worst ? r : worst;
+    }
+    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)mine, shard);
+    if (shard == 0 && threadIdx.x == 0) {
+        out[0] = (int32_t)total;
+        out[1] = (int32_t)worst;
+        out[2] = (int32_t)(total < out_cap ? total : out_cap);
+        out[3] = (int32_t)cap;
+    }
+    const WbDet *src = det + (size_t)shard * cap;
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(out + 4);
+    float4 *boxes = reinterpret_cast<float4 *>(keys + out_cap);
+    float *scores = reinterpret_cast<float *>(boxes + out_cap);
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+        const uint32_t at = before + i;
+        if (at >= out_cap) break;
+        const WbDet d = src[i];
+        const float sc = inv_scale[d.level];
+        keys[at] = ((unsigned long long)(uint32_t)d.level << 54) | ((unsigned long long)d.r << 40) |
+                   ((unsigned long long)d.c << 26) | (unsigned long long)at;
+        boxes[at] = make_float4((float)d.c * sc, (float)d.r * sc, (float)((int)d.c + n) * sc, (float)((int)d.r + m) * sc);
+        scores[at] = d.score;
+    }
+}
+
 #define WB_CASC_CONFIGS(X) X(8, 4) X(4, 4) X(2, 4) X(1, 4) X(8, 8) X(4, 8) X(2, 8) X(1, 8) X(2, 16) X(1, 16)
 
 template <int D>
@@ -1030,6 +1076,25 @@ extern "C" int wb_det_pack_launch(void *stream, const WbDet *det, const uint32_t
     WB_REQUIRE(reinterpret_cast<uintptr_t>(packed) % 16 == 0, "wb_det_pack_launch: packed must be 16-byte aligned");
     hipLaunchKernelGGL(det_pack_kernel, dim3(WB_DET_SHARDS), dim3(256), 0, (hipStream_t)stream, det, det_count,
                        shard_capacity, packed, packed_capacity);
+    WB_HIP_CHECK(hipGetLastError());
+    return WB_OK;
+}
+
+extern "C" int wb_det_finish_launch(void *stream, const WbDet *det, const uint32_t *det_count, uint32_t shard_capacity,
+                                    const float *inv_scale, int n_levels, int max_rows, int max_cols, int m, int n,
+                                    void *out, uint32_t out_capacity) {
+    WB_REQUIRE(det_count && out && inv_scale, "wb_det_finish_launch: null pointer");
+    WB_REQUIRE(det || shard_capacity == 0, "wb_det_finish_launch: det is null but capacity > 0");
+    WB_REQUIRE(reinterpret_cast<uintptr_t>(out) % 16 == 0, "wb_det_finish_launch: out must be 16-byte aligned");
+    WB_REQUIRE(out_capacity % 2 == 0, "wb_det_finish_launch: out_capacity must be even (16-byte aligned sections)");
+    // the sort key holds level in 10 bits, r and c in 14 bits each, the packed position in 26
+    if (n_levels > (1 << 10) || max_rows > (1 << 14) || max_cols > (1 << 14) || out_capacity > (1u << 26)) {
+        wb_set_error("wb_det_finish_launch: %d levels of up to %d x %d windows, %u records do not fit the 10/14/14/26-bit key",
+                     n_levels, max_rows, max_cols, out_capacity);
+        return WB_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(det_finish_kernel, dim3(WB_DET_SHARDS), dim3(256), 0, (hipStream_t)stream, det, det_count,
+                       shard_capacity, inv_scale, m, n, reinterpret_cast<int32_t *>(out), out_capacity);
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;
 }

@@ -221,6 +221,7 @@ class PyramidEngine:
         self.epoch = 0
         self.det_capacity = int(det_capacity)
         self._h_packed = self._h_alive = self._fetch_ev = None
+        self._final = self._h_final = self._h_final_views = self._inv_scales_d = None
         self._alloc_det()
         if exact_single:
             # a channel function on a bare image: no resize happens, so the clip range is (-inf, +inf)
@@ -499,6 +500,53 @@ class PyramidEngine:
             recs = np.concatenate([recs, self.packed[rows:1 + total].cpu().numpy()])
         alive = self._h_alive.numpy()[:, :, :T].astype(np.int64)
         return recs, alive
+
+    def fetch_final(self, dm, stt):
+        """fetch() for Model.detect on ONE image: wb_det_finish_launch leaves sort keys, boxes and scores of all
+        valid records behind one header; they come back with ONE copy and ONE event wait together with alive[B, L, T].
+        Returns (keys uint64 [n] (level << 54 | r << 40 | c << 26 | position), boxes float32 [rows, 4], scores
+        float32 [rows], alive int64 [B, L, T]) -- keys unsorted, boxes / scores indexed by a key's position -- or
+        None when this form does not apply (a batch, a pyramid beyond the key's bit fields, more than _FETCH_ROWS
+        detections): use fetch() then.  Grows the detection buffer and scans again if a shard overflowed."""
+        import torch
+        p = self.plan
+        if self.batch != 1 or p.n_levels > 1024 or p.n_levels == 0:
+            return None
+        if max(int(lv["u"]) for lv in p.levels) > 16384 or max(int(lv["v"]) for lv in p.levels) > 16384:
+            return None
+        P, T = self._FETCH_ROWS, dm.n_stages
+        nbytes = 16 + P * 28
+        if self._final is None:
+            self._final = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            self._h_final = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+            self._inv_scales_d = torch.from_numpy(self.inv_scales()).to(self.dev)
+            self._fetch_ev = self._fetch_ev or torch.cuda.Event()
+            h = self._h_final.numpy()
+            self._h_final_views = (h[:16].view(np.int32), h[16:16 + 8 * P].view(np.uint64),
+                                   h[16 + 8 * P:16 + 24 * P].view(np.float32).reshape(P, 4), h[16 + 24 * P:].view(np.float32))
+        max_u = max(int(lv["u"]) for lv in p.levels)
+        max_v = max(int(lv["v"]) for lv in p.levels)
+        while True:
+            if self._h_alive is None or self._h_alive.shape != stt["alive"].shape:
+                self._h_alive = torch.empty(stt["alive"].shape, dtype=torch.int32).pin_memory()
+            nat.check(self.lib.wb_det_finish_launch(nat.stream_ptr(), nat.ptr(self.detb.recs), nat.ptr(self.detb.counts),
+                                                    self.detb.cap, nat.ptr(self._inv_scales_d), p.n_levels, max_u, max_v,
+                                                    dm.m, dm.n, nat.ptr(self._final), P), "wb_det_finish_launch")
+            self._h_final.copy_(self._final, non_blocking=True)
+            self._h_alive.copy_(stt["alive"], non_blocking=True)
+            self._fetch_ev.record()
+            self._fetch_ev.synchronize()
+            hdr, keys, boxes, scores = self._h_final_views
+            total, worst = int(hdr[0]), int(hdr[1])
+            if worst <= self.detb.cap:
+                break
+            self.det_capacity = (int(worst * 1.5) + 16) * nat.WB_DET_SHARDS
+            self._alloc_det()
+            stt = self.run_cascade(dm, ranks=stt.get("ranks", False))
+        if total > P:
+            return None
+        alive = self._h_alive.numpy()[:, :, :T].astype(np.int64)
+        return keys[:total], boxes, scores, alive
 
     def sorted_detections(self, n=None):
         """Detections ordered by (image, level, r, c) as an int32 [n, 4] tensor of WbDet records."""

@@ -82,8 +82,9 @@ class Model:
         theta.  A tree's arrays are frozen (made read-only) once they have been uploaded, so a later
         in-place edit of an array raises instead of leaving a stale copy on the GPU; replace the
         DTree to change a stage."""
-        # (theta by repr: the float kind matters to theta_as_f32, and NaN compares unequal to itself)
-        sig = (tuple(self.shape), tuple(map(id, self.classifier)), tuple(map(repr, self.theta)))
+        # (theta by value AND kind: the float kind matters to theta_as_f32; a NaN theta still matches itself -- tuple
+        # comparison takes identical objects as equal -- and 128 reprs per call were a tenth of Model.detect's host time)
+        sig = (tuple(self.shape), tuple(map(id, self.classifier)), tuple(self.theta), tuple(map(type, self.theta)))
         if self._device is None or self._device[0] != sig:
             dev = _engine.DeviceCascade(self.shape, self.classifier, self.theta)
             for w in self.classifier:
@@ -141,14 +142,14 @@ class Model:
     def detect(self, image) -> Boxes:
         """Detect objects in a 2-D image; returns Boxes with a 'scores' field, levels in pyramid
         order and windows in row-major order within a level, like the reference."""
-        res = self.detect_raw(image)
+        res = self.detect_raw(image, _full=False)
         out = Boxes(res["boxes"])
         out.set_field("scores", res["scores"])
         return out
 
-    def detect_raw(self, image):
+    def detect_raw(self, image, _full=True):
         """detect() with everything the parity tests compare: boxes, scores, (level, r, c),
-        alive[level, stage]; updates n_loc / n_weak."""
+        alive[level, stage]; updates n_loc / n_weak.  (_full=False: boxes and scores only -- what detect() returns.)"""
         _channels._validate_image(image)
         shrink, n_per_oct, smooth, spec = _channels.read_opts(self.channel_opts)
         m, n, Cc = self.shape
@@ -163,7 +164,7 @@ class Model:
                         scales=[])
         eng.load_images(image)
         stt = eng.run(dm)            # one memset + octaves + channels (straight to this cascade's threshold ranks
-        return self._collect(eng, dm, stt)                         # when it has rank tables) + cascade
+        return self._collect(eng, dm, stt, _full)                  # when it has rank tables) + cascade
 
     def scan_engine(self, eng):
         """Run this cascade over the channel pyramid already resident in `eng` (channels computed
@@ -174,10 +175,26 @@ class Model:
         dm = self.device_cascade()
         return self._collect(eng, dm, eng.run_cascade(dm))
 
-    def _collect(self, eng, dm, stt):
+    def _collect(self, eng, dm, stt, full=True):
         """Results of the scan `stt` of image 0 of `eng`: the dict detect_raw returns; updates n_loc / n_weak."""
         m, n, Cc = self.shape
         T = len(self)
+        fin = eng.fetch_final(dm, stt)                    # ONE host synchronisation: sort keys, boxes, scores, statistics
+        if fin is not None:
+            # get_boxes and the (level, r, c) keys were formed on the device (wb_det_finish_launch): the host sorts
+            # the keys -- unique, so any sort kind gives the reference order -- and gathers
+            keys, boxes_d, scores_d, alive = fin
+            alive = alive[0].reshape(eng.plan.n_levels, T)
+            self.n_loc += eng.plan.n_loc(m, n)
+            self.n_weak += int(alive.sum())
+            ks = np.sort(keys)
+            at = (ks & np.uint64((1 << 26) - 1)).astype(np.intp)
+            res = dict(boxes=boxes_d[at], scores=scores_d[at], alive=alive, scales=list(eng.plan.scales))
+            if full:
+                res.update(level=(ks >> np.uint64(54)).astype(np.int32),
+                           r=((ks >> np.uint64(40)) & np.uint64(0x3fff)).astype(np.int64),
+                           c=((ks >> np.uint64(26)) & np.uint64(0x3fff)).astype(np.int64))
+            return res
         recs, alive = eng.fetch(dm, stt)                  # ONE host synchronisation: packed records + statistics
         alive = alive[0].reshape(eng.plan.n_levels, T)
         n_det = recs.shape[0]
