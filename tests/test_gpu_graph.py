@@ -95,3 +95,48 @@ def test_config3_batch_of_64_1080p_images():
         assert np.array_equal(res["level"][sel], ref["level"]) and np.array_equal(res["r"][sel], ref["r"])
         assert np.array_equal(res["c"][sel], ref["c"]) and np.array_equal(bits(res["scores"][sel]), bits(ref["scores"]))
         assert np.array_equal(bits(res["boxes"][sel]), bits(ref["boxes"]))
+
+
+@pytest.mark.parametrize("channels", sorted(MODELS))
+def test_model_detect_replays_one_graph_per_cascade_vs_oracle(channels):
+    """Model.detect runs eagerly once and replays ONE captured graph (memset .. read-back copies) from the second call
+    on: every call -- eager, replayed, replayed again after the detection buffer had to grow, and with a second
+    cascade taking over the engine in between -- must give the oracle's boxes, scores, order and statistics."""
+    from waldboost_amd import engine as E
+    M = wb.load(os.path.join(GOLDEN, "models", MODELS[channels]))
+    H, W = 300, 420
+    E._ENGINES.clear()
+    imgs = [synth_image(H, W, 7100 + i) for i in range(4)]
+    refs = [oracle_detect(M, im) for im in imgs]
+
+    def check(model, im, ref):
+        before = (model.n_loc, model.n_weak)
+        res = model.detect_raw(im)
+        assert np.array_equal(res["alive"], ref["alive"])
+        assert np.array_equal(res["level"], ref["level"]) and np.array_equal(res["r"], ref["r"]) and np.array_equal(res["c"], ref["c"])
+        assert np.array_equal(bits(res["scores"]), bits(ref["scores"])) and np.array_equal(bits(res["boxes"]), bits(ref["boxes"]))
+        assert model.n_weak - before[1] == int(ref["alive"].sum()) and model.n_loc > before[0]
+        b = model.detect(im)
+        assert np.array_equal(bits(b.get()), bits(ref["boxes"])) and np.array_equal(bits(b.get_field("scores")), bits(ref["scores"]))
+
+    for im, ref in zip(imgs, refs):              # call 1 eager, the rest replays (each check() makes two calls)
+        check(M, im, ref)
+    eng = next(iter(E._ENGINES.values()))
+    stt = eng._casc_state(M.device_cascade())
+    assert stt.get("graph") is not None and stt["detect_calls"] >= 8
+    # a detection buffer too small for the image: the replay reports the overflow, the buffer grows, the graph is dropped
+    # and captured again against the new buffer
+    assert refs[0]["scores"].size > 64
+    eng.det_capacity = 64
+    eng._alloc_det()
+    assert "graph" not in stt
+    for im, ref in zip(imgs, refs):
+        check(M, im, ref)
+    assert eng.detb.cap * nat.WB_DET_SHARDS > 64 and stt.get("graph") is not None
+    # another cascade on the same engine (one cascade resident per engine): the first one's graph goes with its state
+    M2 = wb.load(os.path.join(GOLDEN, "models", MODELS[channels]))
+    M2.theta = [t - 0.25 if np.isfinite(t) else t for t in M2.theta]
+    ref2 = oracle_detect(M2, imgs[1])
+    check(M2, imgs[1], ref2)
+    check(M, imgs[2], refs[2])
+    check(M2, imgs[3], oracle_detect(M2, imgs[3]))

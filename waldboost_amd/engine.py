@@ -18,6 +18,7 @@ from .chanfunc import SPECS
 from .plan import PyramidPlan, N_CHANNELS
 
 _TORCH_DT = {}
+_NO_DETECT_GRAPH = bool(int(os.environ.get("WB_NO_DETECT_GRAPH", "0")))
 _NO_RANKS = bool(os.environ.get("WB_NO_RANKS"))     # diagnostic: float32 channels + planar float tile everywhere
 
 
@@ -221,7 +222,7 @@ class PyramidEngine:
         self.epoch = 0
         self.det_capacity = int(det_capacity)
         self._h_packed = self._h_alive = self._fetch_ev = None
-        self._final = self._h_final = self._h_final_views = self._inv_scales_d = None
+        self._final = self._h_final = self._h_final_views = self._inv_scales_d = self._final_dims = None
         self._alloc_det()
         if exact_single:
             # a channel function on a bare image: no resize happens, so the clip range is (-inf, +inf)
@@ -273,6 +274,8 @@ class PyramidEngine:
         self.det_capacity = cap * nat.WB_DET_SHARDS
         self.detb = DetBuffer(cap, self.dev, counts=self._counts)
         self.packed = None            # header + all valid records back to back (wb_det_pack_launch), allocated on first use
+        for stt in getattr(self, "_casc", {}).values():
+            stt.pop("graph", None)    # (a captured detect_run holds the old buffer's address)
 
     # ------------------------------------------------------------------ input
     def load_images(self, images):
@@ -501,22 +504,21 @@ class PyramidEngine:
         alive = self._h_alive.numpy()[:, :, :T].astype(np.int64)
         return recs, alive
 
-    def fetch_final(self, dm, stt):
-        """fetch() for Model.detect on ONE image: wb_det_finish_launch leaves sort keys, boxes and scores of all
-        valid records behind one header; they come back with ONE copy and ONE event wait together with alive[B, L, T].
-        Returns (keys uint64 [n] (level << 54 | r << 40 | c << 26 | position), boxes float32 [rows, 4], scores
-        float32 [rows], alive int64 [B, L, T]) -- keys unsorted, boxes / scores indexed by a key's position -- or
-        None when this form does not apply (a batch, a pyramid beyond the key's bit fields, more than _FETCH_ROWS
-        detections): use fetch() then.  Grows the detection buffer and scans again if a shard overflowed."""
+    def _final_ready(self):
+        """Whether Model.detect's one-copy read-back form applies to this engine (one image, a pyramid within the sort
+        key's 10 / 14 / 14-bit fields); allocates its buffers on first use."""
         import torch
         p = self.plan
-        if self.batch != 1 or p.n_levels > 1024 or p.n_levels == 0:
-            return None
-        if max(int(lv["u"]) for lv in p.levels) > 16384 or max(int(lv["v"]) for lv in p.levels) > 16384:
-            return None
-        P, T = self._FETCH_ROWS, dm.n_stages
-        nbytes = 16 + P * 28
+        if self._final_dims is None:
+            ok = self.batch == 1 and 0 < p.n_levels <= 1024
+            mu = max((int(lv["u"]) for lv in p.levels), default=0)
+            mv = max((int(lv["v"]) for lv in p.levels), default=0)
+            self._final_dims = (ok and mu <= 16384 and mv <= 16384, mu, mv)
+        if not self._final_dims[0]:
+            return False
         if self._final is None:
+            P = self._FETCH_ROWS
+            nbytes = 16 + P * 28
             self._final = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
             self._h_final = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
             self._inv_scales_d = torch.from_numpy(self.inv_scales()).to(self.dev)
@@ -524,16 +526,35 @@ class PyramidEngine:
             h = self._h_final.numpy()
             self._h_final_views = (h[:16].view(np.int32), h[16:16 + 8 * P].view(np.uint64),
                                    h[16 + 8 * P:16 + 24 * P].view(np.float32).reshape(P, 4), h[16 + 24 * P:].view(np.float32))
-        max_u = max(int(lv["u"]) for lv in p.levels)
-        max_v = max(int(lv["v"]) for lv in p.levels)
+        return True
+
+    def _final_enqueue(self, dm, stt):
+        """wb_det_finish_launch + the two read-back copies into page-locked memory (no synchronisation)."""
+        import torch
+        if self._h_alive is None or self._h_alive.shape != stt["alive"].shape:
+            self._h_alive = torch.empty(stt["alive"].shape, dtype=torch.int32).pin_memory()
+        nat.check(self.lib.wb_det_finish_launch(nat.stream_ptr(), nat.ptr(self.detb.recs), nat.ptr(self.detb.counts),
+                                                self.detb.cap, nat.ptr(self._inv_scales_d), self.plan.n_levels,
+                                                self._final_dims[1], self._final_dims[2], dm.m, dm.n,
+                                                nat.ptr(self._final), self._FETCH_ROWS), "wb_det_finish_launch")
+        self._h_final.copy_(self._final, non_blocking=True)
+        self._h_alive.copy_(stt["alive"], non_blocking=True)
+
+    def fetch_final(self, dm, stt, enqueued=False):
+        """fetch() for Model.detect on ONE image: wb_det_finish_launch leaves sort keys, boxes and scores of all
+        valid records behind one header; they come back with ONE copy and ONE event wait together with alive[B, L, T].
+        Returns (keys uint64 [n] (level << 54 | r << 40 | c << 26 | position), boxes float32 [rows, 4], scores
+        float32 [rows], alive int64 [B, L, T]) -- keys unsorted, boxes / scores indexed by a key's position -- or
+        None when this form does not apply (a batch, a pyramid beyond the key's bit fields, more than _FETCH_ROWS
+        detections): use fetch() then.  Grows the detection buffer and scans again if a shard overflowed.
+        enqueued: the launch and the copies are already in the stream (detect_run's graph replay)."""
+        if not self._final_ready():
+            return None
+        P, T = self._FETCH_ROWS, dm.n_stages
         while True:
-            if self._h_alive is None or self._h_alive.shape != stt["alive"].shape:
-                self._h_alive = torch.empty(stt["alive"].shape, dtype=torch.int32).pin_memory()
-            nat.check(self.lib.wb_det_finish_launch(nat.stream_ptr(), nat.ptr(self.detb.recs), nat.ptr(self.detb.counts),
-                                                    self.detb.cap, nat.ptr(self._inv_scales_d), p.n_levels, max_u, max_v,
-                                                    dm.m, dm.n, nat.ptr(self._final), P), "wb_det_finish_launch")
-            self._h_final.copy_(self._final, non_blocking=True)
-            self._h_alive.copy_(stt["alive"], non_blocking=True)
+            if not enqueued:
+                self._final_enqueue(dm, stt)
+            enqueued = False
             self._fetch_ev.record()
             self._fetch_ev.synchronize()
             hdr, keys, boxes, scores = self._h_final_views
@@ -547,6 +568,32 @@ class PyramidEngine:
             return None
         alive = self._h_alive.numpy()[:, :, :T].astype(np.int64)
         return keys[:total], boxes, scores, alive
+
+    def detect_run(self, dm):
+        """Model.detect's whole device sequence for the resident image -- one memset, octaves, channels, cascade,
+        wb_det_finish_launch, the two read-back copies -- and its one synchronisation; from the second call with the
+        same cascade on it is replayed as ONE hipGraph (one enqueue instead of seven, no gaps between the kernels).
+        Returns what fetch_final returns, or None (then: run(dm) has happened, use fetch())."""
+        import torch
+        stt = self._casc_state(dm)
+        if not self._final_ready():
+            self.run(dm)
+            return None
+        g = stt.get("graph")
+        if g is None and stt.get("detect_calls", 0) >= 1 and not _NO_DETECT_GRAPH:
+            # (the first call ran eagerly: every lazily allocated buffer exists, the kernels are loaded)
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                self.run(dm)
+                self._final_enqueue(dm, stt)
+            stt["graph"] = g
+        stt["detect_calls"] = stt.get("detect_calls", 0) + 1
+        if g is None:
+            self.run(dm)
+            return self.fetch_final(dm, stt)
+        g.replay()
+        return self.fetch_final(dm, stt, enqueued=True)
 
     def sorted_detections(self, n=None):
         """Detections ordered by (image, level, r, c) as an int32 [n, 4] tensor of WbDet records."""

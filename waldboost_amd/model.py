@@ -163,8 +163,10 @@ class Model:
                         r=np.empty(0, np.int64), c=np.empty(0, np.int64), alive=np.zeros((0, T), np.int64),
                         scales=[])
         eng.load_images(image)
-        stt = eng.run(dm)            # one memset + octaves + channels (straight to this cascade's threshold ranks
-        return self._collect(eng, dm, stt, _full)                  # when it has rank tables) + cascade
+        # one memset + octaves + channels (straight to this cascade's threshold ranks when it has rank tables) + cascade
+        # + boxes and sort keys + the read-back: one hipGraph replay from the second call on
+        fin = eng.detect_run(dm)
+        return self._collect(eng, dm, eng._casc_state(dm), _full, fin)
 
     def scan_engine(self, eng):
         """Run this cascade over the channel pyramid already resident in `eng` (channels computed
@@ -175,17 +177,21 @@ class Model:
         dm = self.device_cascade()
         return self._collect(eng, dm, eng.run_cascade(dm))
 
-    def _collect(self, eng, dm, stt, full=True):
-        """Results of the scan `stt` of image 0 of `eng`: the dict detect_raw returns; updates n_loc / n_weak."""
+    def _collect(self, eng, dm, stt, full=True, fin=False):
+        """Results of the scan `stt` of image 0 of `eng`: the dict detect_raw returns; updates n_loc / n_weak.
+        fin: what eng.detect_run returned for this scan (False: fetch it here)."""
         m, n, Cc = self.shape
         T = len(self)
-        fin = eng.fetch_final(dm, stt)                    # ONE host synchronisation: sort keys, boxes, scores, statistics
+        if fin is False:
+            fin = eng.fetch_final(dm, stt)                # ONE host synchronisation: sort keys, boxes, scores, statistics
         if fin is not None:
             # get_boxes and the (level, r, c) keys were formed on the device (wb_det_finish_launch): the host sorts
             # the keys -- unique, so any sort kind gives the reference order -- and gathers
             keys, boxes_d, scores_d, alive = fin
             alive = alive[0].reshape(eng.plan.n_levels, T)
-            self.n_loc += eng.plan.n_loc(m, n)
+            if "n_loc" not in stt:
+                stt["n_loc"] = eng.plan.n_loc(m, n)
+            self.n_loc += stt["n_loc"]
             self.n_weak += int(alive.sum())
             ks = np.sort(keys)
             at = (ks & np.uint64((1 << 26) - 1)).astype(np.intp)
