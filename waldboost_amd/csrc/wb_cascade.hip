@@ -60,6 +60,15 @@ struct CascArgs {
 
 __device__ inline float as_f(int32_t x) { return __int_as_float(x); }
 
+// theta == -inf for a wave-uniform theta, decided on the SCALAR unit: the bits go through an opaque scalar register so
+// the comparison stays an integer one (written as a float test -- or as a plain bit test, which the compiler turns
+// back into a float test -- it was a vector compare per stage)
+__device__ inline bool never_rejects(float theta) {
+    int bits = __float_as_int(theta);
+    asm volatile("" : "+s"(bits));
+    return bits == (int)0xff800000;
+}
+
 // Diagnostic build only (make STAMPS=1): wave 0 of every workgroup stores s_memrealtime at its phase
 // boundaries into a private slot (plain stores, nothing reads them in the kernel); the host turns
 // them into mean wall-clock per phase (wb_debug_cascade_stamps).  Never part of a measured build.
@@ -309,9 +318,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
     const int tA = T < S0 ? T : S0;
     static_assert(S0 <= 64, "one lane per phase-A stage");
     uint32_t entered = 0;                 // windows of this wave entering stage `lane` (phase A)
-    for (int t = 0; t < tA; t += G) {
+#pragma unroll
+    for (int t = 0; t < S0; t += G) {
+        if (t >= tA) break;
         Stage<D> st[G];
-        const int32_t *sp = stages + (size_t)__builtin_amdgcn_readfirstlane(t) * SD;
+        const int32_t *sp = stages + (size_t)t * SD;
 #pragma unroll
         for (int g = 0; g < G; ++g) st[g].load(sp + g * SD);
         float p[G][RPW];
@@ -325,10 +336,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
             int cnt = 0;
 #pragma unroll
             for (int j = 0; j < RPW; ++j) cnt += __popcll(lm[j]);
-            entered = lane == t + g ? (uint32_t)cnt : entered;   // lane t keeps stage t's count: one LDS atomic per wave after the phase
+            // lane t keeps stage t's count (one LDS atomic per wave after the phase): both operands are scalars, so
+            // this is ONE v_writelane instead of a move, a compare and a select
+            // (the loops are fully unrolled: the lane index is an immediate)
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(entered) : "s"(cnt), "n"(t + g));
             // theta == -inf never rejects (a NaN sum would fail `>=`): folded into the mask, not a branch,
             // so the RPW rows stay in one basic block and share the stage's constants in registers
-            const unsigned long long never = st[g].theta != -INFINITY ? 0ull : ~0ull;
+            // (the bits of the scalar theta compared as an integer: a scalar compare; as a float compare it was
+            // a vector instruction per stage)
+            const unsigned long long never = never_rejects(st[g].theta) ? ~0ull : 0ull;
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
                 hs[j] = hs[j] + p[g][j];                      // (a dead window's sum is never read again)
@@ -422,6 +438,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
                 int pos = (int)e.x;
                 float h = __uint_as_float(e.y);
                 int wbase = ((pos >> 6) * pitch + (pos & 63)) * px_stride;
+                uint32_t ent_c = 0;           // this chunk's windows entering stage t_begin + lane
                 for (int t = t_begin; t < t_end; t += G) {
                     if (am == 0ull) break;
                     Stage<D> st[G];
@@ -434,12 +451,16 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         if (t + g >= t_end) break;
-                        int cnt = __popcll(am);
-                        entered_b += lane == t + g - t_begin ? (uint32_t)cnt : 0u;
+                        // the chunk's count for stage t + g goes into lane (t + g - t_begin) of ent_c with ONE v_writelane
+                        // (value and lane index are both scalars; two scalar operands exceed the constant-bus limit, so
+                        // the index travels in m0) instead of a move, a compare and a select
+                        const int cnt = __popcll(am);
+                        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(ent_c) : "s"(cnt), "s"(t + g - t_begin) : "m0");
                         h = h + p[g];                        // (a dead window's sum is never read again)
-                        am &= __ballot(h >= st[g].theta) | (st[g].theta != -INFINITY ? 0ull : ~0ull);
+                        am &= __ballot(h >= st[g].theta) | (never_rejects(st[g].theta) ? ~0ull : 0ull);
                     }
                 }
+                entered_b += ent_c;
                 int cnt = __popcll(am);
                 if (cnt) {
                     // in place: n_out + rank <= qb + lane, and this wave already holds chunk qb in registers
