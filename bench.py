@@ -71,12 +71,18 @@ N_SIMD, CLOCK_GHZ = 256 * 4, 2.4          # MI355X_MICROARCH.md: 256 CUs x 4 SIM
 
 
 def issue_bound(roof, batch, channels):
-    """The bound that actually binds these kernels: vector-instruction issue.  From the committed SQ counters
-    (three rocprofv3 --pmc passes, profiles/r02/sq_counters.json, instructions per image), a wave64 VALU
-    instruction holds its SIMD's issue port for 2 cycles at best (MI355X_MICROARCH.md: v_fma_f32 2 cycles) and
-    for 4 when it is a conversion or an fp64 operation (tools/valu_rate_probe.hip), so
-        floor_us = (VALU + CVT + F64) instructions x 2 cycles / (1024 SIMDs x 2.4 GHz)
-    is the time the dominant kernel's instruction stream needs if no wave ever waits; frac = floor / measured."""
+    """The bound that binds these kernels: vector-instruction issue.  Measured on this GPU
+    (tools/valu_class_probe.hip, profiles/r02/valu_issue_classes.txt), at 4 waves per SIMD a wave64 VALU instruction
+    holds its SIMD for ~2.5 cycles if it is a plain fp32 add / multiply / fmac (or a 32-bit add / and / or / shift-right /
+    move) on vector-register operands, and for ~4.3 cycles otherwise (compares, selects, min / max, conversions, fp64,
+    anything with a scalar-register operand).  From the committed SQ counters (three rocprofv3 --pmc passes,
+    instructions per image):
+        floor_us = (fp32 add + mul + fma instructions x 2.5 + all other VALU instructions x 4.3) cycles
+                   / (1024 SIMDs x 2.4 GHz)
+    -- a LOWER estimate of the issue time (integer adds / logic ops of the fast class are counted as fast only when the
+    counters single them out: they do not, so they are priced at 4.3; fp32 operations with a scalar operand are priced
+    at 2.5).  frac = floor / measured.  wave_time = where a wave's lifetime goes, from the same counters: issuing
+    instructions, ready but waiting for an issue slot, waiting on memory / LDS / a barrier."""
     path = os.path.join(PROFILE_DIR, "sq_counters.json")
     if roof is None or channels != "grad_hist" or not os.path.exists(path):
         return None
@@ -86,12 +92,19 @@ def issue_bound(roof, batch, channels):
         return None
     g = lambda name: k.get(name + "_per_image", 0.0) * batch
     valu, salu = g("SQ_INSTS_VALU"), g("SQ_INSTS_SALU")
-    slow = g("SQ_INSTS_VALU_CVT") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_FMA_F64")
-    floor_us = (valu + slow) * 2.0 / (N_SIMD * CLOCK_GHZ * 1e3)
-    return {"kernel": roof["kernel"], "bound": "valu_issue", "valu_insts_per_launch": valu, "of_which_4_cycle": slow,
+    fast = g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_FMA_F32")
+    floor_us = (fast * 2.5 + (valu - fast) * 4.3) / (N_SIMD * CLOCK_GHZ * 1e3)
+    wc = g("SQ_WAVE_CYCLES")
+    wave_time = None
+    if wc:
+        wave_time = {"issuing": g("SQ_ACTIVE_INST_ANY") / wc, "waiting_for_issue_slot": g("SQ_WAIT_INST_ANY") / wc,
+                     "waiting_on_data_or_barrier": g("SQ_WAIT_ANY") / wc}
+    return {"kernel": roof["kernel"], "bound": "valu_issue", "valu_insts_per_launch": valu, "of_which_fp32_add_mul_fma": fast,
             "salu_insts_per_launch": salu, "floor_us": floor_us, "measured_us": roof["avg_launch_ms"] * 1e3,
-            "frac": floor_us / (roof["avg_launch_ms"] * 1e3), "counters": "profiles/r02/sq_counters.json",
-            "note": "2 issue cycles per wave64 VALU instruction, 4 for conversions and fp64; 1024 SIMDs at 2.4 GHz"}
+            "frac": floor_us / (roof["avg_launch_ms"] * 1e3), "wave_time": wave_time,
+            "counters": "profiles/r02/sq_counters.json",
+            "note": "2.5 issue cycles per wave64 fp32 add/mul/fma, 4.3 per other VALU instruction (measured classes); "
+                    "1024 SIMDs at 2.4 GHz"}
 
 
 def event_time_ms(fn, iters, torch):

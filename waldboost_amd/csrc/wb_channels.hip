@@ -296,6 +296,34 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
     // Levels at their octave's own size (scale 1: every level i=0 with even dims) resample with
     // weights (1, 0): t = v*1*1 + 0 + 0 + 0 = v exactly -> plain copy.
     const bool ident = (L.src_h == L.nh) && (L.src_w == L.nw);
+    if constexpr (sizeof(T) == 1) {
+        // ... and for a tile that lies inside the level (no clamped coordinate) the copy is done four pixels at a time: one
+        // (unaligned) dword load, four byte conversions, two 8-byte LDS stores -- every load of the tile in flight at
+        // once, no taps.  One level in eight is such a level and it is the largest of its octave (21 % of all tiles).
+        constexpr int RWD = (RW + 3) / 4;
+        if (ident && ry0 >= 0 && ry0 + RH <= L.nh && rx0 >= 0 && rx0 + 4 * RWD <= L.nw) {
+            static_assert(RW % 2 == 0, "pixel pairs");
+            typedef uint32_t __attribute__((aligned(1))) u32u;
+            constexpr int NE = RH * RWD, PER = (NE + 255) / 256;
+            uint32_t v[PER];
+            int at[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                int e = tid + 256 * i;
+                e = e < NE ? e : NE - 1;                              // (duplicates rewrite the same values)
+                const int k = e / RWD, d = e - k * RWD;
+                v[i] = *reinterpret_cast<const u32u *>(src + (int64_t)(ry0 + k) * L.src_w + rx0 + 4 * d);
+                at[i] = k * RW + 4 * d;
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                float2 *dst = reinterpret_cast<float2 *>(R + at[i]);
+                dst[0] = make_float2((float)(v[i] & 0xffu), (float)((v[i] >> 8) & 0xffu));
+                if (at[i] % RW + 2 < RW) dst[1] = make_float2((float)((v[i] >> 16) & 0xffu), (float)(v[i] >> 24));
+            }
+            return;
+        }
+    }
     // uint8 images: the tile's source patch (rows r_lo..r_hi, columns c_lo..c_hi of the octave) is
     // first copied to LDS with coalesced dword loads; the 4 taps of every pixel are then LDS byte
     // reads.  (Fetched straight from HBM they were 4 byte-gathers per pixel and the texture-address
