@@ -269,7 +269,9 @@ template <int S_, int TU_, int TV_, bool SMOOTH_> struct TileGeom {
     // and the shrunk tile Sh (live from step 2 on).  Source patch capacity: no larger than a
     // float4 Sh, so that R + region stay under 40 KiB (4 workgroups per CU); tiles of the most
     // down-scaled levels of an octave that do not fit take the direct path
-    static constexpr int PROWS = 2 * RH + 4, PPITCH = ((SU * SV * 16) / PROWS) & ~3;
+    // (shrink 2: 74 rows x 256 bytes instead of 80 x 236 -- the most down-scaled level of an octave of 8, zoom step
+    // 1.834, needs 72 rows of 254 bytes and took the direct path before)
+    static constexpr int PROWS = S == 2 ? 74 : 2 * RH + 4, PPITCH = ((SU * SV * 16) / PROWS) & ~3;
     static constexpr int SH_BYTES = SU * SV * 16;
     static constexpr int PATCH_BYTES = PROWS * PPITCH;
 };
