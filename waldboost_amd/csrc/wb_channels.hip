@@ -323,6 +323,9 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                 dst[0] = make_float2((float)(v[i] & 0xffu), (float)((v[i] >> 8) & 0xffu));
                 if (at[i] % RW + 2 < RW) dst[1] = make_float2((float)((v[i] >> 16) & 0xffu), (float)(v[i] >> 24));
             }
+            WB_CSTAMP(1);
+            WB_CSTAMP(2);
+            WB_CSTAMP(3);
             return;
         }
     }
