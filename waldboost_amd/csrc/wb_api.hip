@@ -289,6 +289,14 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
             reinterpret_cast<float *>(rec)[2 * NI + NL] = theta[s];
         }
     }
+    if (const char *path = getenv("WB_DUMP_STAGES")) {       // diagnostic: the three record tables as raw int32
+        if (FILE *f = fopen(path, "wb")) {
+            const int32_t hdr[4] = {n_stages + G, SD, D, M->bin_ok};
+            fwrite(hdr, 4, 4, f);
+            for (int mode = 0; mode < 3; ++mode) fwrite(packs[mode].data(), 4, packs[mode].size(), f);
+            fclose(f);
+        }
+    }
     {
         const std::vector<int32_t> &packed = packs[0];
         hipError_t e = hipMalloc((void **)&M->stages_dev, packed.size() * 4);
