@@ -31,6 +31,7 @@
 // bit-identical to the reference's `hs += ...; mask = hs >= theta`.
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "wb_common.h"
@@ -318,40 +319,49 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) vo
     const int tA = T < S0 ? T : S0;
     static_assert(S0 <= 64, "one lane per phase-A stage");
     uint32_t entered = 0;                 // windows of this wave entering stage `lane` (phase A)
+    // FULL: the cascade has at least S0 stages (the usual case) -- phase A is then straight-line code, no per-stage
+    // bound checks: the scheduler is free to request a stage's record while the previous stage is being evaluated
+    auto phase_a = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int t = 0; t < S0; t += G) {
-        if (t >= tA) break;
-        Stage<D> st[G];
-        const int32_t *sp = stages + (size_t)t * SD;
+        for (int t = 0; t < S0; t += G) {
+            if (!FULL && t >= tA) break;
+            Stage<D> st[G];
+            const int32_t *sp = stages + (size_t)t * SD;
 #pragma unroll
-        for (int g = 0; g < G; ++g) st[g].load(sp + g * SD);
-        float p[G][RPW];
+            for (int g = 0; g < G; ++g) st[g].load(sp + g * SD);
+            float p[G][RPW];
 #pragma unroll
-        for (int g = 0; g < G; ++g)
+            for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int j = 0; j < RPW; ++j) p[g][j] = st[g].template eval<U8>(tile, base[j]);
+                for (int j = 0; j < RPW; ++j) p[g][j] = st[g].template eval<U8>(tile, base[j]);
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if (t + g >= tA) break;
-            int cnt = 0;
+            for (int g = 0; g < G; ++g) {
+                if (!FULL && t + g >= tA) break;
+                int cnt = 0;
 #pragma unroll
-            for (int j = 0; j < RPW; ++j) cnt += __popcll(lm[j]);
-            // lane t keeps stage t's count (one LDS atomic per wave after the phase): both operands are scalars, so
-            // this is ONE v_writelane instead of a move, a compare and a select
-            // (the loops are fully unrolled: the lane index is an immediate)
-            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(entered) : "s"(cnt), "n"(t + g));
-            // theta == -inf never rejects (a NaN sum would fail `>=`): folded into the mask, not a branch,
-            // so the RPW rows stay in one basic block and share the stage's constants in registers
-            // (the bits of the scalar theta compared as an integer: a scalar compare; as a float compare it was
-            // a vector instruction per stage)
-            const unsigned long long never = never_rejects(st[g].theta) ? ~0ull : 0ull;
+                for (int j = 0; j < RPW; ++j) cnt += __popcll(lm[j]);
+                // lane t keeps stage t's count (one LDS atomic per wave after the phase): both operands are scalars, so
+                // this is ONE v_writelane instead of a move, a compare and a select
+                // (the loops are fully unrolled: the lane index is an immediate)
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(entered) : "s"(cnt), "n"(t + g));
+                // theta == -inf never rejects (a NaN sum would fail `>=`): folded into the mask, not a branch,
+                // so the RPW rows stay in one basic block and share the stage's constants in registers
+                // (the bits of the scalar theta compared as an integer: a scalar compare; as a float compare it was
+                // a vector instruction per stage)
+                const unsigned long long never = never_rejects(st[g].theta) ? ~0ull : 0ull;
 #pragma unroll
-            for (int j = 0; j < RPW; ++j) {
-                hs[j] = hs[j] + p[g][j];                      // (a dead window's sum is never read again)
-                lm[j] &= __ballot(hs[j] >= st[g].theta) | never;
+                for (int j = 0; j < RPW; ++j) {
+                    hs[j] = hs[j] + p[g][j];                      // (a dead window's sum is never read again)
+                    lm[j] &= __ballot(hs[j] >= st[g].theta) | never;
+                }
             }
         }
-    }
+    };
+    if (tA == S0)
+        phase_a(std::true_type{});
+    else
+        phase_a(std::false_type{});
     if (entered) atomicAdd(&hist[lane], entered);
     if (a.dbg & 4) return;
 
