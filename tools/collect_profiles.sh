@@ -9,6 +9,7 @@ O=${1:-gpurun_out/prof}
 rm -rf $O && mkdir -p $O
 timeout -k 10 500 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -5 $O/bench_default.err; exit 1; }
 echo "default bench done"
+timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_flags.json 2>> $O/bench_default.err || exit 1
 timeout -k 10 300 python3 bench.py --batch 64 --steps 10 --warmup 2 --pool 2 --streams 2 --no-cpu-baseline > $O/bench_batch64.json 2>> $O/bench_default.err || exit 1
 timeout -k 10 300 python3 bench.py --channels grad_hist_4_u1 --no-cpu-baseline > $O/bench_grad_hist_4_u1.json 2>> $O/bench_default.err || exit 1
 timeout -k 10 300 python3 bench.py --channels grad_hist_4_u1 --batch 64 --steps 10 --warmup 2 --pool 2 --streams 2 --no-cpu-baseline > $O/bench_grad_hist_4_u1_batch64.json 2>> $O/bench_default.err || exit 1
