@@ -217,28 +217,38 @@ def main():
     #      --no-graph) runs once more and what IT wrote -- detections and alive[level, stage] of the first and the
     #      last image of the batch -- is compared with the oracle, bit for bit
     parity = None
-    if rank == 0 and args.only == "all" and not args.stages:
-        from util import oracle_detect
-        e = engines[0]
+
+    def poison(e):
         e.detb.counts.fill_(0x7fffffff)                      # stale values the step must overwrite
         e._casc_state(dm)["alive"].fill_(-1)
-        steps[0]()
-        torch.cuda.synchronize()
+
+    def gate(e, path):
+        """What the last launch left in engine `e` -- detections and alive[level, stage] of the first and the last
+        image of its batch -- against the oracle, bit for bit."""
+        from util import oracle_detect
         if e.detb.max_count() > e.detb.cap:
             raise SystemExit("bench: detection buffer overflow in the parity gate")
         d = e.sorted_detections().cpu().numpy().view(nat.DET_DTYPE).reshape(-1)
         alive = e._casc_state(dm)["alive"][:, :, :len(M)].cpu().numpy().astype(np.int64)
         checked = []
+        j0 = engines.index(e)
         for b in sorted({0, B - 1}):
             db = d[d["image"] == b]
-            ref = oracle_detect(M, synth_image(H, W, (rank * P) * B + b))
+            ref = oracle_detect(M, synth_image(H, W, (rank * P + j0) * B + b))
             ok = (np.array_equal(db["level"], ref["level"]) and np.array_equal(db["r"], ref["r"]) and
                   np.array_equal(db["c"], ref["c"]) and np.array_equal(db["score"].view(np.uint32), ref["scores"].view(np.uint32)) and
                   np.array_equal(alive[b], ref["alive"]))
             if not ok:
                 raise SystemExit(f"bench: image {b} of the replayed step differs from the oracle -- refusing to time a wrong kernel")
-            checked.append({"image": f"seed {b}", "detections": int(ref["scores"].size), "eval_cost": ref["n_weak"] / ref["n_loc"]})
-        parity = {"path": "eager launches" if args.no_graph else "hipGraph replay", "images": checked, "bit_exact": True}
+            checked.append({"image": f"seed {(rank * P + j0) * B + b}", "detections": int(ref["scores"].size),
+                            "eval_cost": ref["n_weak"] / ref["n_loc"]})
+        return {"path": path, "images": checked, "bit_exact": True}
+
+    if rank == 0 and args.only == "all" and not args.stages:
+        poison(engines[0])
+        steps[0]()
+        torch.cuda.synchronize()
+        parity = gate(engines[0], "eager launches" if args.no_graph else "hipGraph replay per step")
 
     gath = comm = None
     if world > 1:
@@ -305,8 +315,18 @@ def main():
             for st in cap_lanes:
                 if st is not main:
                     main.wait_stream(st)
+        # the gate again, on THIS graph: what its replay leaves in the first and the last engine it drives
+        checked = sorted({0, min(P, args.steps) - 1})
+        if parity is not None:
+            for j in checked:
+                poison(engines[j])
         region.replay()                                      # (first replay outside the timed regions)
         torch.cuda.synchronize()
+        if parity is not None:
+            parity = {"path": "one hipGraph replay per timed region", "bit_exact": True,
+                      "engines": [dict(gate(engines[j], ""), engine=j) for j in checked]}
+            for g in parity["engines"]:
+                g.pop("path")
     dts = []
     for rep in range(max(1, args.repeats)):
         torch.cuda.synchronize()
