@@ -143,9 +143,9 @@ def main():
     ap.add_argument("--stages", type=int, default=0, help="diagnostic: keep only the first N stages of the cascade")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--region-graph", choices=["auto", "on", "off"], default="auto",
-                    help="capture the K steps of a timed region into ONE hipGraph (one launch per region) instead of "
-                         "one replay per step; auto: when K <= 64 -- a short region is dominated by the K launches and "
-                         "the staggered start of the streams (K=20: +6 %%), a long one runs 3 %% faster step by step")
+                    help="capture the K steps of a timed region into one hipGraph per stream (n_streams launches per region) "
+                         "instead of one replay per step; auto: when K <= 64 -- a short region is dominated by the K launches "
+                         "and the staggered start of the streams (K=20: +5 %%), a long one amortises both")
     ap.add_argument("--only", choices=["all", "channels", "cascade", "octaves"], default="all",
                     help="profile helper: launch only one kernel group in the timed loop")
     args = ap.parse_args()
@@ -293,37 +293,45 @@ def main():
             main.wait_stream(comm)
 
     run_steps(0, args.warmup)
-    # One GPU, graph mode: the K steps of a timed region -- K x (memset, octaves, channels, cascade), spread over the
-    # streams exactly as run_steps spreads them -- are captured ONCE into a single hipGraph with one branch per
-    # stream, and a region is one replay of it: one launch per region instead of K, no staggered start of the
-    # streams.  (With several ranks the steps carry a collective each and stay separate launches.)
+    # One GPU, graph mode, short regions: the K steps of a timed region -- K x (memset, octaves, channels, cascade), spread
+    # over the streams exactly as run_steps spreads them -- are captured ONCE, one hipGraph per stream holding that
+    # stream's steps in order, and a region is one replay per stream: n_streams launches per region instead of K, every
+    # stream fed from its first microsecond (tools/region_launch_probe.py: 20 steps take 1.45 ms replayed step by step,
+    # 1.40 ms as four per-stream graphs).  (With several ranks the steps carry a collective each and stay separate.)
     region = None
     use_region = args.region_graph == "on" or (args.region_graph == "auto" and args.steps <= 64)
     if world == 1 and args.only == "all" and not args.no_graph and use_region:
         eager = [(lambda e=e: e.run(dm)) for e in engines]
         torch.cuda.synchronize()
-        region = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(region):
-            main = torch.cuda.current_stream()
-            cap_lanes = lanes if n_streams > 1 else [main]
-            for st in cap_lanes:
-                if st is not main:
-                    st.wait_stream(main)
-            for i in range(args.steps):
-                with torch.cuda.stream(cap_lanes[(i % P) % n_streams]):
-                    eager[i % P]()
-            for st in cap_lanes:
-                if st is not main:
-                    main.wait_stream(st)
-        # the gate again, on THIS graph: what its replay leaves in the first and the last engine it drives
+        region = []
+        for l, st in enumerate(lanes if n_streams > 1 else [None]):
+            mine = [i % P for i in range(args.steps) if (i % P) % n_streams == l]
+            if not mine:
+                continue
+            g = torch.cuda.CUDAGraph()
+            with (torch.cuda.graph(g, stream=st) if st is not None else torch.cuda.graph(g)):
+                for j in mine:
+                    eager[j]()
+            region.append((st, g))
+
+        def run_region():
+            # (no cross-stream waits: a region starts after a device-wide synchronisation and ends with one)
+            for st, g in region:
+                if st is None:
+                    g.replay()
+                else:
+                    with torch.cuda.stream(st):
+                        g.replay()
+
+        # the gate again, on THESE graphs: what their replay leaves in the first and the last engine they drive
         checked = sorted({0, min(P, args.steps) - 1})
         if parity is not None:
             for j in checked:
                 poison(engines[j])
-        region.replay()                                      # (first replay outside the timed regions)
+        run_region()                                         # (first replay outside the timed regions)
         torch.cuda.synchronize()
         if parity is not None:
-            parity = {"path": "one hipGraph replay per timed region", "bit_exact": True,
+            parity = {"path": "one hipGraph replay per stream and timed region", "bit_exact": True,
                       "engines": [dict(gate(engines[j], ""), engine=j) for j in checked]}
             for g in parity["engines"]:
                 g.pop("path")
@@ -335,7 +343,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if region is not None:
-            region.replay()
+            run_region()
         else:
             run_steps(args.warmup + rep * args.steps, args.steps)
         torch.cuda.synchronize()
@@ -410,7 +418,7 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: 1920x1080 uint8, shrink=2 n_per_oct=8 smooth=1 {args.channels}, "
                                    f"window (12,12,4), 128-stage depth-2 cascade, {B} image(s)/step/GPU",
                        "batch_per_gpu": B, "levels": plan.n_levels, "windows_per_image": n_loc,
-                       "launch": "eager" if args.no_graph else ("one hipGraph replay per timed region of K steps" if region is not None
+                       "launch": "eager" if args.no_graph else ("one hipGraph replay per stream and timed region of K steps" if region is not None
                                                                 else "hipGraph replay per step"), "only": args.only,
                        "channels_in_hbm": "uint8 threshold ranks of the cascade (WB_DTYPE_RANK8)" if fused else spec.dtype.name,
                        "streams": n_streams, "pool": P,
