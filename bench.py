@@ -140,6 +140,9 @@ def main():
                          "reference's integer channels (same geometry, uint8 channels, its own calibrated cascade)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                                                       "rehearse the multi-rank loop with several ranks on one GPU)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="diagnostic: run the multi-rank step (pack + all_gather of the detection prefixes on a side stream) "
+                         "with a single rank, to measure what the collective path costs per step")
     ap.add_argument("--stages", type=int, default=0, help="diagnostic: keep only the first N stages of the cascade")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--region-graph", choices=["auto", "on", "off"], default="auto",
@@ -164,17 +167,20 @@ def main():
     import torch.distributed as dist
     local_dev = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_dev)
-    if world > 1:
+    coll = world > 1 or args.force_collective                # the pack + all_gather path
+    if coll:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev), rank=rank, world_size=world)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import waldboost_amd as wb
     from waldboost_amd import _native as nat
     from waldboost_amd.engine import PyramidEngine
     from waldboost_amd.synth import synth_image
-    from waldboost_amd.distributed import DetectionGatherer
+    from waldboost_amd.distributed import RoundGatherer
 
     M = wb.load(MODELS[args.channels])
     spec = wb.channels.channel_spec(M.channel_opts["channels"])
@@ -251,21 +257,44 @@ def main():
         parity = gate(engines[0], "eager launches" if args.no_graph else "hipGraph replay per step")
 
     gath = comm = None
-    if world > 1:
-        # the gathered prefix is sized from what the workload produces (2x the fullest image set, agreed over the
-        # ranks), not from the buffer's capacity: a few hundred KB per rank instead of the whole detection buffer
+    n_streams = max(1, min(args.streams, P))
+    lanes = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream()]
+    if coll:
+        # Several ranks: every step ends with its engine's valid records packed (wb_det_pack_launch, inside the step's
+        # graph) into the engine's slot of a send buffer, and every round of P steps ends with ONE all_gather of the P
+        # slots on a side stream -- overlapped with the next round, no host synchronisation.  (One collective per step
+        # -- launch, two events, a stream hop: ~50 us of host time -- made the step host-bound: 95 us against 67.)
+        # The gathered prefix is sized from what the workload produces (2x the fullest image set, agreed over the
+        # ranks), not from the buffer's capacity: a few hundred KB per rank instead of the whole detection buffer.
         most = torch.tensor([max(int(e.detb.counts.sum().item()) for e in engines)], dtype=torch.int64,
                             device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(most, op=dist.ReduceOp.MAX)
         rows = max(1024, 2 * int(most.item()))
-        gath = [DetectionGatherer(rows, engines[0].dev) for e in engines]
+        gath = RoundGatherer(rows, P, engines[0].dev)
         comm = torch.cuda.Stream()
-        ev_done = [torch.cuda.Event() for _ in engines]      # step i's kernels finished
-        ev_comm = [torch.cuda.Event() for _ in engines]      # step i's gather finished
-        packs = [None] * len(engines)
+        ev_done = [torch.cuda.Event() for _ in engines]      # engine j's step (incl. its pack) finished
+        ev_comm = [torch.cuda.Event() for _ in range(gath.SETS)]   # the collective that read send[set] finished
+        if args.only == "all" and not args.no_graph:
+            # the step graph again, once per buffer set, with the pack inside
+            def capture_with_pack(e, out):
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    e.run(dm)
+                    e.pack(out)
+                return g
+            coll_steps = [[capture_with_pack(e, gath.send[w][j]).replay for j, e in enumerate(engines)] for w in range(gath.SETS)]
+        else:
+            coll_steps = [[(lambda j=j, w=w: (steps[j](), engines[j].pack(gath.send[w][j]))) for j in range(P)]
+                          for w in range(gath.SETS)]
 
-    n_streams = max(1, min(args.streams, P))
-    lanes = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream()]
+    def flush_round(w):
+        """One all_gather of buffer set w on the side stream, behind the steps that packed into it."""
+        with torch.cuda.stream(comm):
+            for j in range(P):
+                comm.wait_event(ev_done[j])
+            gath.gather(w)
+            ev_comm[w].record(comm)
 
     def run_steps(k0, k):
         main = torch.cuda.current_stream()
@@ -276,20 +305,19 @@ def main():
             j = i % P                                        # engine j always runs on stream j % n_streams
             st = lanes[j % n_streams]
             with torch.cuda.stream(st):
-                if world > 1:
-                    st.wait_event(ev_comm[j])                # buffer j free again
-                steps[j]()
-                if world > 1:
-                    packs[j] = engines[j].pack()             # valid records back to back behind a header (one tiny launch)
+                if coll:
+                    w = (i // P) % gath.SETS
+                    st.wait_event(ev_comm[w])                # send[w] free again: the collective two rounds back is done
+                    coll_steps[w][j]()
                     ev_done[j].record(st)
-                    with torch.cuda.stream(comm):
-                        comm.wait_event(ev_done[j])
-                        gath[j].gather(packs[j])
-                        ev_comm[j].record(comm)
+                else:
+                    steps[j]()
+            if coll and (j == P - 1 or i == k0 + k - 1):
+                flush_round((i // P) % gath.SETS)            # (also at the end of a region: all its work ends inside it)
         for st in lanes:
             if st is not main:
                 main.wait_stream(st)
-        if world > 1:
+        if coll:
             main.wait_stream(comm)
 
     run_steps(0, args.warmup)
@@ -300,7 +328,7 @@ def main():
     # 1.40 ms as four per-stream graphs).  (With several ranks the steps carry a collective each and stay separate.)
     region = None
     use_region = args.region_graph == "on" or (args.region_graph == "auto" and args.steps <= 64)
-    if world == 1 and args.only == "all" and not args.no_graph and use_region:
+    if not coll and args.only == "all" and not args.no_graph and use_region:
         eager = [(lambda e=e: e.run(dm)) for e in engines]
         torch.cuda.synchronize()
         region = []
@@ -338,7 +366,7 @@ def main():
     dts = []
     for rep in range(max(1, args.repeats)):
         torch.cuda.synchronize()
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -347,11 +375,11 @@ def main():
         else:
             run_steps(args.warmup + rep * args.steps, args.steps)
         torch.cuda.synchronize()
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize()
         dts.append(time.perf_counter() - t0)
-    if world > 1:
+    if coll:
         tt = torch.tensor(dts, dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)            # every region: the slowest rank's time
         dts = [float(x) for x in tt.tolist()]
@@ -422,7 +450,7 @@ def main():
                                                                 else "hipGraph replay per step"), "only": args.only,
                        "channels_in_hbm": "uint8 threshold ranks of the cascade (WB_DTYPE_RANK8)" if fused else spec.dtype.name,
                        "streams": n_streams, "pool": P,
-                       "collective": "all_gather of the packed detection prefix per step (side stream)" if world > 1 else "none"},
+                       "collective": "one all_gather of the P packed detection prefixes per round of P steps (side stream)" if coll else "none"},
             "mpixels_per_s": world * args.steps * B * H * W / dt / 1e6,
             "images_per_s": world * args.steps * B / dt,
             "pipeline_roofline_frac": (windows / dt) * (ab["total"] / n_loc) / (HBM_PEAK_GBS * 1e9 * world),
@@ -432,7 +460,7 @@ def main():
             "roofline": roof, "issue_bound": issue_bound(roof, B, args.channels), "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if coll:
         dist.destroy_process_group()
 
 

@@ -174,3 +174,54 @@ def test_capacity_agreement_prefix_gather_and_alive_reduce_world_size_2():
                           np.stack([want[k].astype(np.int64) for k in ("image", "level", "r", "c")]))
     assert sorted(got["score"].tolist()) == sorted(want["score"].tolist())
     assert a["tot"] == b["tot"] == (np.arange(12).reshape(3, 4) * 3).tolist()
+
+
+def _round_gatherer_worker(rank, world, port, q):
+    """RoundGatherer on gloo/CPU: two buffer sets, three slots per rank, ranks with different detection counts."""
+    import torch
+    import torch.distributed as dist
+    from waldboost_amd.distributed import RoundGatherer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows, slots = 16, 3
+        g = RoundGatherer(rows, slots, "cpu")
+        want = {}
+        for which in range(g.SETS):
+            for slot in range(slots):
+                for r in range(world):
+                    n = (3 * r + 5 * slot + 7 * which) % 11            # 0 .. 10 records
+                    d = np.zeros(n, nat.DET_DTYPE)
+                    d["image"], d["level"] = 0, np.arange(n) % 3
+                    d["r"], d["c"] = 100 * r + np.arange(n), 10 * slot + which
+                    d["score"] = np.arange(n, dtype=np.float32) + 0.25 * r
+                    want[(which, slot, r)] = d
+                    if r == rank:
+                        g.send[which][slot].copy_(_packed(d, rows))
+            g.gather(which)
+        for which in range(g.SETS):
+            for slot in range(slots):
+                got = g.merged(which, slot, [1] * world)
+                exp = np.concatenate([want[(which, slot, r)] for r in range(world)])
+                exp["image"] = np.concatenate([np.full(want[(which, slot, r)].size, r) for r in range(world)])
+                exp = exp[np.lexsort((exp["c"], exp["r"], exp["level"], exp["image"]))]
+                assert np.array_equal(got, exp), (which, slot)
+        q.put((rank, "ok"))
+    except Exception as e:                                   # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_round_gatherer_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + os.getpid() % 200
+    procs = [ctx.Process(target=_round_gatherer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: "ok", 1: "ok"}, res

@@ -76,6 +76,58 @@ class DetectionGatherer:
         return out[order]
 
 
+class RoundGatherer:
+    """DetectionGatherer for a pipeline of `slots` engines per rank: the engines pack straight into their slot of ONE
+    send buffer (PyramidEngine.pack(out=gatherer.send[set][slot])) and ONE all_gather moves all slots of a round --
+    one collective launch per `slots` steps instead of one per step (the per-step launch, ~50 us of host time with its
+    events, made the multi-rank step host-bound).  Two buffer sets alternate between rounds, so the packs of round
+    r + 1 never wait for the collective of round r."""
+
+    SETS = 2
+
+    def __init__(self, rows, slots, device, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.rows, self.slots = int(rows), int(slots)
+        self.send = [torch.zeros((self.slots, 1 + self.rows, 4), dtype=torch.int32, device=device) for _ in range(self.SETS)]
+        self.recv = [torch.zeros((self.world, self.slots, 1 + self.rows, 4), dtype=torch.int32, device=device)
+                     for _ in range(self.SETS)]
+        self._host_staged = torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
+
+    def gather(self, which):
+        """All ranks' send[which] -> recv[which] on every rank (on the current stream; no host synchronisation with RCCL)."""
+        if self._host_staged:                      # (gloo rehearsal on one GPU: staged through the host)
+            import torch
+            recv = torch.empty((self.recv[which].numel() // 4, 4), dtype=torch.int32)
+            self.dist.all_gather_into_tensor(recv, self.send[which].view(-1, 4).cpu(), group=self.group)
+            self.recv[which].view(-1, 4).copy_(recv)
+            return
+        # (flat [n, 4] views: the ranks' blocks concatenate along dim 0, the form every backend takes)
+        self.dist.all_gather_into_tensor(self.recv[which].view(-1, 4), self.send[which].view(-1, 4), group=self.group)
+
+    def merged(self, which, slot, images_per_rank):
+        """Host-side merge of one slot of a gathered round, as DetectionGatherer.merged."""
+        from ._native import DET_DTYPE
+        recv = self.recv[which][:, slot].cpu().numpy()
+        parts, base = [], 0
+        for r in range(self.world):
+            total, worst, present, cap = (int(x) for x in recv[r, 0])
+            if worst > cap:
+                raise OverflowError(f"rank {r}: a detection shard holds {worst} records, capacity {cap}")
+            if total > self.rows:
+                raise OverflowError(f"rank {r}: {total} detections, the gathered prefix holds {self.rows}")
+            d = recv[r, 1: 1 + total].copy().view(DET_DTYPE).reshape(-1)
+            d["image"] += base
+            parts.append(d)
+            base += int(images_per_rank[r])
+        out = np.concatenate(parts) if parts else np.zeros(0, DET_DTYPE)
+        return out[np.lexsort((out["c"], out["r"], out["level"], out["image"]))]
+
+
 # ------------------------------------------------------------------------------ the end-of-batch exchange
 def _comm_device(group=None):
     """Where collective payloads live: the GPU for RCCL ("nccl"), the host for gloo."""

@@ -461,10 +461,16 @@ class PyramidEngine:
             self._alloc_det()
             self.run_cascade(dm, ranks=self._casc_state(dm).get("ranks", False))
 
-    def pack(self):
+    def pack(self, out=None):
         """Pack the valid records of all shards behind a 4-word header (wb_det_pack_launch) into self.packed --
-        the form a collective or a host read-back takes; no synchronisation."""
+        the form a collective or a host read-back takes; no synchronisation.  out: an int32 [1 + rows, 4] device
+        tensor (16-byte aligned, e.g. a rank's slot of a collective's send buffer) to pack into instead -- the header
+        then says how many of the valid records fitted its `rows`."""
         import torch
+        if out is not None:
+            nat.check(self.lib.wb_det_pack_launch(nat.stream_ptr(), nat.ptr(self.detb.recs), nat.ptr(self.detb.counts),
+                                                  self.detb.cap, nat.ptr(out), out.shape[0] - 1), "wb_det_pack_launch")
+            return out
         if self.packed is None:
             self.packed = torch.empty((1 + self.detb.NS * self.detb.cap, 4), dtype=torch.int32, device=self.dev)
         nat.check(self.lib.wb_det_pack_launch(nat.stream_ptr(), nat.ptr(self.detb.recs), nat.ptr(self.detb.counts),
