@@ -140,3 +140,25 @@ def test_model_detect_replays_one_graph_per_cascade_vs_oracle(channels):
     check(M2, imgs[1], ref2)
     check(M, imgs[2], refs[2])
     check(M2, imgs[3], oracle_detect(M2, imgs[3]))
+
+
+def test_model_detect_with_more_detections_than_the_read_back_prefix():
+    """Model.detect's one-copy read-back holds _FETCH_ROWS records; a scan with more detections (here: a prefix shrunk to
+    64 rows) falls back to the packed-record read-back -- eager and from the replayed graph alike -- with the same result."""
+    from waldboost_amd import engine as E
+    M = wb.load(os.path.join(GOLDEN, "models", MODELS["grad_hist"]))
+    img = synth_image(300, 420, 7301)
+    ref = oracle_detect(M, img)
+    assert ref["scores"].size > 64
+    E._ENGINES.clear()
+    old = E.PyramidEngine._FETCH_ROWS
+    E.PyramidEngine._FETCH_ROWS = 64
+    try:
+        for _ in range(3):                               # eager, capture + replay, replay
+            res = M.detect_raw(img)
+            assert np.array_equal(res["level"], ref["level"]) and np.array_equal(res["r"], ref["r"]) and np.array_equal(res["c"], ref["c"])
+            assert np.array_equal(bits(res["scores"]), bits(ref["scores"])) and np.array_equal(bits(res["boxes"]), bits(ref["boxes"]))
+            assert np.array_equal(res["alive"], ref["alive"])
+    finally:
+        E.PyramidEngine._FETCH_ROWS = old
+        E._ENGINES.clear()
