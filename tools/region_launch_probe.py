@@ -27,7 +27,26 @@ for j, e in enumerate(engines):
         for _ in range(K // P):
             e.run(dm)
     lane_graphs.append(g)
+head_graphs, tail_graphs = [], []
+for j, e in enumerate(engines):
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=lanes[j]):
+        e.run(dm)
+    head_graphs.append(g)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=lanes[j]):
+        for _ in range(K // P - 1):
+            e.run(dm)
+    tail_graphs.append(g)
 torch.cuda.synchronize()
+
+def region_d():
+    for j in range(P):
+        with torch.cuda.stream(lanes[j]):
+            head_graphs[j].replay()
+    for j in range(P):
+        with torch.cuda.stream(lanes[j]):
+            tail_graphs[j].replay()
 
 def region_a():
     for i in range(K):
@@ -61,4 +80,7 @@ def timeit(fn, name):
 timeit(region_a, "(a) one replay per step, round-robin")
 timeit(region_b, "(b) one graph per stream, one host thread")
 timeit(region_c, "(c) one graph per stream, one host thread each")
+timeit(region_d, "(d) per stream: a 1-step graph, then a 4-step graph")
+timeit(region_b, "(b) again")
+timeit(region_d, "(d) again")
 stop = True; start.wait()
