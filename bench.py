@@ -6,10 +6,14 @@
 A *step* is one pass of the hot path -- octave pyramid, fused grad_hist channel pyramid and the
 dense 128-stage depth-2 cascade scan (BASELINE.json configs[1]) -- over one batch of B synthetic
 1920x1080 uint8 images already resident in HBM, replayed from one hipGraph.  Consecutive steps
-cycle through a pool of different resident images.  With N>1 (launched by torch.distributed.run,
-one rank per GPU) every rank runs the same per-GPU workload on its own images ("weak" scaling)
-and each step ends with the RCCL all-gather of the fixed-size detection prefix, issued on a side
-stream so it overlaps the next step's kernels.
+cycle through a pool of different resident images.  With N>1 there is one rank per GPU: either
+the caller starts them (torch.distributed.run; RANK / WORLD_SIZE in the environment) or, when
+WORLD_SIZE is not set, bench.py starts torch.distributed.run itself -- before torch is imported
+or the GPU touched -- and exits with its code (the reference's own parallel idiom is a process pool
+over images, scripts/waldboost-detect.py:64-67).  Every rank runs the same per-GPU workload on its
+own images ("weak" scaling: BASELINE configs[3] is --gpus 8 --batch 64) and every round of steps
+ends with the RCCL all-gather of the fixed-size detection prefixes, issued on a side stream so
+that it overlaps the next round's kernels.
 
 Rank 0 prints ONE JSON line: candidate windows/s (whole job), plus
   roofline     -- the dominant kernel's algorithmic HBM bytes per launch / its average launch
@@ -120,6 +124,23 @@ def event_time_ms(fn, iters, torch):
     return e0.elapsed_time(e1) / iters
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks with torch.distributed.run (one process
+    per GPU, rendezvous on 127.0.0.1 at a free port), pass the flags through, wait, return its exit code.  Runs before
+    torch is imported and before anything touches the GPU -- the ranks are fresh child processes."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # (dmabuf IPC: what RCCL needs on this driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,13 +172,32 @@ def main():
                          "and the staggered start of the streams (K=20: +5 %%), a long one amortises both")
     ap.add_argument("--only", choices=["all", "channels", "cascade", "octaves"], default="all",
                     help="profile helper: launch only one kernel group in the timed loop")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the ranks, rendezvous (gloo on the CPU), let rank 0 print what it would run, stop: checks "
+                         "the launch path on a machine without GPUs")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
+    if args.dry_launch:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        seen = torch.zeros(world, dtype=torch.int64)
+        dist.all_gather_into_tensor(seen, torch.tensor([rank * 10 + local_rank], dtype=torch.int64))
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "n_gpus": args.gpus, "world_size_reported": dist.get_world_size(),
+                              "ranks": [int(x) // 10 for x in seen], "local_ranks": [int(x) % 10 for x in seen],
+                              "backend": args.backend, "steps": args.steps, "warmup": args.warmup, "batch_per_gpu": args.batch}))
+        dist.destroy_process_group()
+        return
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline and args.only == "all":
@@ -165,7 +205,13 @@ def main():
 
     import torch
     import torch.distributed as dist
-    local_dev = local_rank % max(torch.cuda.device_count(), 1)
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs a GPU (torch.cuda.device_count() == 0); --dry-launch checks the launch path without one")
+    if world > n_dev and args.backend == "nccl":
+        raise SystemExit(f"--gpus {world} with backend nccl (RCCL) needs {world} GPUs, this node shows {n_dev}; "
+                         "--backend gloo rehearses the multi-rank loop with several ranks on one GPU")
+    local_dev = local_rank % n_dev
     torch.cuda.set_device(local_dev)
     coll = world > 1 or args.force_collective                # the pack + all_gather path
     if coll:
@@ -245,12 +291,12 @@ def main():
                   np.array_equal(db["c"], ref["c"]) and np.array_equal(db["score"].view(np.uint32), ref["scores"].view(np.uint32)) and
                   np.array_equal(alive[b], ref["alive"]))
             if not ok:
-                raise SystemExit(f"bench: image {b} of the replayed step differs from the oracle -- refusing to time a wrong kernel")
+                raise SystemExit(f"bench: rank {rank}: image {b} of the replayed step differs from the oracle -- refusing to time a wrong kernel")
             checked.append({"image": f"seed {(rank * P + j0) * B + b}", "detections": int(ref["scores"].size),
                             "eval_cost": ref["n_weak"] / ref["n_loc"]})
         return {"path": path, "images": checked, "bit_exact": True}
 
-    if rank == 0 and args.only == "all" and not args.stages:
+    if args.only == "all" and not args.stages:               # on EVERY rank: each checks its own engine 0 (its own images)
         poison(engines[0])
         steps[0]()
         torch.cuda.synchronize()
@@ -379,8 +425,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dts.append(time.perf_counter() - t0)
+    per_rank = None
     if coll:
-        tt = torch.tensor(dts, dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        cdev = "cuda" if args.backend == "nccl" else "cpu"
+        mine = torch.tensor([float(np.median(dts)) / args.steps * 1e3, 1.0 if parity is not None else 0.0], dtype=torch.float64, device=cdev)
+        allr = torch.zeros((world, 2), dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(allr, mine.view(1, 2))
+        per_rank = {"ms_per_step": [float(x) for x in allr[:, 0].tolist()], "parity_gate_passed": [bool(x) for x in allr[:, 1].tolist()],
+                    "world_size_reported": dist.get_world_size(), "backend": dist.get_backend()}
+        tt = torch.tensor(dts, dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)            # every region: the slowest rank's time
         dts = [float(x) for x in tt.tolist()]
     dt = float(np.median(dts))
@@ -456,7 +509,7 @@ def main():
             "pipeline_roofline_frac": (windows / dt) * (ab["total"] / n_loc) / (HBM_PEAK_GBS * 1e9 * world),
             "value_spread": {"repeats": len(dts), "min": windows / max(dts), "max": windows / min(dts),
                              "ms_per_step_min": min(dts) / args.steps * 1e3, "ms_per_step_max": max(dts) / args.steps * 1e3},
-            "kernels": kern, "parity": parity, "through_api": through_api,
+            "kernels": kern, "parity": parity, "ranks": per_rank, "through_api": through_api,
             "roofline": roof, "issue_bound": issue_bound(roof, B, args.channels), "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -225,3 +225,35 @@ def test_round_gatherer_two_ranks_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == {0: "ok", 1: "ok"}, res
+
+
+def _run_bench(*flags):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags], env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus N` with a bare environment (how the driver calls it at N=1) must start N ranks itself,
+    rendezvous, and let rank 0 print ONE JSON line; --dry-launch stops there, before anything needs a GPU."""
+    import json
+    r = _run_bench("--gpus", "2", "--dry-launch", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["dry_launch"] and out["n_gpus"] == 2 and out["world_size_reported"] == 2
+    assert out["ranks"] == [0, 1] and out["local_ranks"] == [0, 1] and out["steps"] == 2
+
+
+def test_bench_propagates_a_failing_rank():
+    """Without a GPU the real run cannot start: every rank exits non-zero with a clear message and the parent
+    returns that failure instead of hanging or printing a line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--no-cpu-baseline", "--steps", "2")
+    assert r.returncode != 0
+    assert "needs a GPU" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())

@@ -162,3 +162,29 @@ def test_model_detect_with_more_detections_than_the_read_back_prefix():
     finally:
         E.PyramidEngine._FETCH_ROWS = old
         E._ENGINES.clear()
+
+
+def test_captured_step_refuses_to_replay_after_the_engine_reallocated():
+    """A captured graph addresses the control block and the detection buffer; once either has been re-allocated
+    (a grown detection buffer here) the replay must raise instead of adding into freed memory."""
+    import torch
+    from waldboost_amd.engine import PyramidEngine
+    M = wb.load(os.path.join(GOLDEN, "mixed_d2_T24.pb"))
+    dm = M.device_cascade()
+    H, W = 240, 320
+    e = PyramidEngine(H, W, np.uint8, 2, 8, 1, batch=1, det_capacity=64)       # one record per shard: overflows
+    img = synth_image(H, W, 3)
+    e.load_images(img)
+    g = e.capture(dm)
+    g.replay()
+    torch.cuda.synchronize()
+    ref = oracle_detect(M, img)
+    assert ref["scores"].size > 64
+    n = e.ensure_capacity(dm)                                                   # grows the buffer, scans again
+    assert n == ref["scores"].size
+    with pytest.raises(RuntimeError, match="stale"):
+        g.replay()
+    g2 = e.capture(dm)
+    g2.replay()
+    torch.cuda.synchronize()
+    assert_image_matches(engine_results(e, e._casc_state(dm), len(M))[0], ref)

@@ -67,3 +67,63 @@ def test_detect_sharded_two_ranks_one_gpu():
         assert np.array_equal(np.array(out[r][2]), ref["alive"].sum(axis=0))
         assert out[r][3] == (M.n_loc, M.n_weak)
     assert out[0][4] == out[1][4] and out[1][4][0] > 16     # rank 1 overflowed; both ranks grew to the same capacity
+
+
+def _edge_worker(rank, world, port, q):
+    """float64 DEVICE tensors (held as float64 with a dtype code), an empty shard on rank 1, then images too small for
+    any pyramid level: no rank may raise alone or block the other in a collective."""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import waldboost_amd as wb
+        from waldboost_amd.distributed import detect_sharded, shard_range
+        from waldboost_amd.synth import synth_image
+        here = os.path.dirname(os.path.abspath(__file__))
+        M = wb.load(os.path.join(here, "golden", "mixed_d2_T24.pb"))
+        lo, hi = shard_range(1, rank, world)                                       # rank 0: one image, rank 1: none
+        imgs = np.stack([synth_image(200, 264, 900 + b) for b in range(lo, hi)] or [np.zeros((200, 264), np.uint8)])[: hi - lo]
+        t = torch.from_numpy(imgs.astype(np.float64)).cuda()
+        det, alive, total = detect_sharded(M, t)
+        tiny = torch.zeros((hi - lo, 6, 40), dtype=torch.float64, device="cuda")  # h < 8: no octave, no level
+        det0, alive0, total0 = detect_sharded(M, tiny)
+        try:
+            detect_sharded(M, torch.zeros((1, 200, 264), dtype=torch.float16, device="cuda"))
+            unsupported = "no error"
+        except NotImplementedError:
+            unsupported = "NotImplementedError"
+        q.put((rank, None if det is None else det.tobytes(), alive.shape, total.tolist(), (M.n_loc, M.n_weak),
+               (None if det0 is None else det0.size, alive0.shape, total0.shape, unsupported)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_detect_sharded_float64_tensors_empty_shard_and_no_levels():
+    import waldboost_amd as wb
+    from waldboost_amd import _native as nat
+    from waldboost_amd.synth import synth_image
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_edge_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict((r, rest) for r, *rest in (q.get(timeout=300) for _ in range(2)))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    M = wb.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mixed_d2_T24.pb"))
+    ref = M.detect_raw(synth_image(200, 264, 900).astype(np.float64))
+    got = np.frombuffer(out[0][0], nat.DET_DTYPE)
+    assert out[1][0] is None and got.size == ref["scores"].size > 0
+    assert np.array_equal(got["level"], ref["level"]) and np.array_equal(got["r"], ref["r"].astype(np.uint16))
+    assert np.array_equal(got["score"].view(np.uint32), ref["scores"].view(np.uint32))
+    assert out[0][1][0] == 1 and out[1][1][0] == 0
+    for r in range(2):
+        assert np.array_equal(np.array(out[r][2]), ref["alive"]) and out[r][3] == (M.n_loc, M.n_weak)
+        assert out[r][4][1:] == ((1 - r, 0, len(M)), (0, len(M)), "NotImplementedError")
+    assert out[0][4][0] == 0 and out[1][4][0] is None

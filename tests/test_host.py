@@ -156,6 +156,49 @@ def test_model_container_semantics():
     assert len(M.get_boxes(np.array([]), np.array([]), 0.5)) == 0
 
 
+def test_device_cascade_cache_follows_the_content_of_the_stage_list(monkeypatch):
+    """The reference's classifier / theta lists and the trees' arrays are public and mutable (model.py:62-67,
+    training.py:24-31): any edit -- in place, by rebinding an array, by swapping stages -- must rebuild the GPU copy,
+    no edit must not, and nothing of the caller's may be frozen."""
+    from waldboost_amd import engine
+
+    class FakeCascade:
+        built = 0
+
+        def __init__(self, shape, classifier, theta):
+            FakeCascade.built += 1
+            self.snapshot = [w.threshold.copy() for w in classifier]
+
+    monkeypatch.setattr(engine, "DeviceCascade", FakeCascade)
+    M = wb.load(os.path.join(GOLDEN, "mixed_d2_T24.pb"))
+    d0 = M.device_cascade()
+    assert M.device_cascade() is d0 and FakeCascade.built == 1
+    w = M.classifier[3]
+    assert w.threshold.flags.writeable and w.left.flags.writeable
+    w.threshold[0] += 1                                       # in place
+    d1 = M.device_cascade()
+    assert d1 is not d0 and d1.snapshot[3][0] == w.threshold[0] and M.device_cascade() is d1
+    w.prediction = w.prediction.copy()                        # rebound array, same values: harmless either way
+    w.prediction[-1] = 7                                      # ... and then edited in place
+    d2 = M.device_cascade()
+    assert d2 is not d1 and M.device_cascade() is d2
+    w.feature[0, 0] ^= 1
+    d3 = M.device_cascade()
+    assert d3 is not d2
+    M.theta[2] = np.float64(M.theta[2])                       # same value, other kind (theta_as_f32 depends on it)
+    d4 = M.device_cascade()
+    assert d4 is not d3
+    M.classifier[0], M.classifier[1] = M.classifier[1], M.classifier[0]
+    d5 = M.device_cascade()
+    assert d5 is not d4 and M.device_cascade() is d5
+    # a tree shared by two models stays editable from both sides
+    M2 = wb.Model(M.shape, M.channel_opts)
+    M2.append(w, 0.0)
+    e0 = M2.device_cascade()
+    w.threshold[0] -= 1
+    assert M2.device_cascade() is not e0 and M.device_cascade() is not d5
+
+
 def test_boxes_container():
     b = wb.Boxes(np.arange(8, dtype=np.float32).reshape(2, 4), scores=np.array([1.0, 2.0], np.float32))
     assert len(b) == 2 and b.has_field("scores") and not b.has_field("label")

@@ -994,6 +994,10 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
         return s;
     }();
     for (int i = 0; i < 4; ++i) a.spar[i] = spar.v[i];
+    // the workgroup-wide re-count behind the segment [8, 16) takes every wave's queue as evaluated up to stage 16: a
+    // wave must not leave run_segments for the tail before that stage (an override below 16 would skip stages 8..15)
+    a.spar[0] = a.spar[0] < 16 ? 16 : a.spar[0];
+    a.spar[2] = a.spar[2] < 16 ? 16 : a.spar[2];
     static const int spar_wg = getenv("WB_CASC_SPAR_WG") ? atoi(getenv("WB_CASC_SPAR_WG")) : 64;
     a.spar_wg = spar_wg;
     dim3 grid((unsigned)n_tiles, (unsigned)batch);

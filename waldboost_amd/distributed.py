@@ -240,10 +240,17 @@ def detect_sharded(model, images, group=None, dst=0):
     b = int(images.shape[0])
     shrink, n_per_oct, smooth, spec = _channels.read_opts(model.channel_opts)
     H, W = int(images.shape[1]), int(images.shape[2])
-    dtype = images.dtype if isinstance(images, np.ndarray) else {"torch.uint8": np.uint8, "torch.float32": np.float32}[str(images.dtype)]
+    dtype = _engine.array_dtype(images)               # (NotImplementedError before any collective: the same on every rank)
     dm = model.device_cascade()
     T = len(model)
     eng = _engine.get_engine(H, W, dtype, shrink, n_per_oct, smooth, max(b, 1), channels=spec)
+    if eng.plan.n_levels == 0:
+        # images smaller than the window: no level, no window, nothing to exchange -- the plan depends on (H, W,
+        # channel_opts) only, so every rank returns here together (reference model.py:171-177 yields nothing either)
+        from ._native import DET_DTYPE
+        import torch.distributed as dist
+        rank = dist.get_rank(group)
+        return (np.zeros(0, DET_DTYPE) if rank == dst else None), np.zeros((b, 0, T), np.int64), np.zeros((0, T), np.int64)
     if b:
         eng.load_images(images)
     scan = _EngineScan(eng, dm)                       # (a rank with an empty shard scans one blank image and drops it)

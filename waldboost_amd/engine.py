@@ -52,6 +52,18 @@ def image_code(np_dtype):
             "and uint32 are supported)") from None
 
 
+def array_dtype(images):
+    """NumPy dtype of an image batch given as an ndarray or a torch tensor, checked against the kernels' image types
+    (NotImplementedError otherwise -- raised before any launch or collective)."""
+    dt = images.dtype if isinstance(images, np.ndarray) else str(images.dtype).replace("torch.", "")
+    try:
+        dt = np.dtype(dt)
+    except TypeError:
+        raise NotImplementedError(f"image dtype {images.dtype} has no HIP kernel") from None
+    image_code(dt)
+    return dt
+
+
 def orientation_constants():
     """cos/sin of the 4 unsigned orientations, built exactly as reference channels.py:43-46
     builds them (NumPy fp64; note cos(pi/2) = 6.1e-17, not 0)."""
@@ -167,6 +179,21 @@ def sort_records(d):
     return d[torch.argsort(key)].contiguous()
 
 
+class CapturedStep:
+    """A hipGraph of one engine's step (PyramidEngine.capture).  The graph holds device ADDRESSES: of the control block
+    and of the detection buffer, both of which the engine re-allocates when they must grow.  replay() refuses to run
+    a graph captured before such a re-allocation (it would add into freed memory) -- capture again."""
+
+    def __init__(self, engine, graph):
+        self.engine, self.graph, self.generation = engine, graph, engine.generation
+
+    def replay(self):
+        if self.generation != self.engine.generation:
+            raise RuntimeError("this captured step is stale: the engine re-allocated its control block or detection "
+                               "buffer after the capture (a longer cascade, or a grown detection buffer); capture again")
+        self.graph.replay()
+
+
 class PyramidEngine:
     _FETCH_ROWS = 4096            # detection records read back with the first copy of fetch()
 
@@ -202,6 +229,7 @@ class PyramidEngine:
         # (three separate fills and the statistics reduction used to be four extra launches per image)
         self._mm_words = self.batch * max(p.n_oct, 1) * 2 * (2 if self.wide_keys else 1)
         self._alive_words = 0
+        self.generation = 0           # bumped whenever a buffer a captured graph may address is re-allocated
         self._alloc_ctrl(0)
         table, total = p.level_table()
         self.chn_stride = int(total)
@@ -239,6 +267,7 @@ class PyramidEngine:
         """(Re)allocate the control block with room for `alive_words` statistics words; the views into it follow."""
         import torch
         old = getattr(self, "ctrl", None)
+        self.generation += 1
         NS = nat.WB_DET_SHARDS
         self._alive_words = int(alive_words)
         self.ctrl = torch.zeros(self._mm_words + NS + max(self._alive_words, 1), dtype=torch.int32, device=self.dev)
@@ -272,6 +301,7 @@ class PyramidEngine:
         the shards."""
         cap = max(16, -(-self.det_capacity // nat.WB_DET_SHARDS))
         self.det_capacity = cap * nat.WB_DET_SHARDS
+        self.generation += 1
         self.detb = DetBuffer(cap, self.dev, counts=self._counts)
         self.packed = None            # header + all valid records back to back (wb_det_pack_launch), allocated on first use
         for stt in getattr(self, "_casc", {}).values():
@@ -424,7 +454,8 @@ class PyramidEngine:
     # ------------------------------------------------------------------ hipGraph
     def capture(self, dm):
         """Capture octaves -> channels -> cascade into one hipGraph (torch.cuda.CUDAGraph on ROCm).
-        Returns the graph; ``graph.replay()`` re-runs the whole pipeline on the resident images."""
+        Returns a CapturedStep; ``.replay()`` re-runs the whole pipeline on the resident images (and raises once the
+        engine has re-allocated a buffer the graph addresses)."""
         import torch
         self._casc_state(dm)
         s = torch.cuda.Stream()
@@ -436,7 +467,7 @@ class PyramidEngine:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self.run(dm)
-        return g
+        return CapturedStep(self, g)
 
     # ------------------------------------------------------------------ results
     def ensure_capacity(self, dm):

@@ -15,7 +15,7 @@ from . import model_pb2
 from .boxes import Boxes, concatenate
 from .channels import channel_pyramid
 from .compare import channel_tensor
-from .training import DTree
+from .training import DTree, _REBINDS
 
 # above this many detections per call the compaction, ordering and boxes stay on the GPU
 _HOST_POST_MAX = 1 << 16
@@ -46,6 +46,7 @@ class Model:
         self.classifier = []
         self.theta = []
         self._device = None
+        self._content = None
         self.reset()
 
     # ---- statistics (reference model.py:69-89)
@@ -76,20 +77,24 @@ class Model:
         self._device = None
 
     def device_cascade(self):
-        """The device-side cascade for the current stage list.  `classifier` and `theta` are plain
-        public lists in the reference and callers edit them in place, so the cached handle is keyed
-        by the lists' current content: the identity of every tree and the value and kind of every
-        theta.  A tree's arrays are frozen (made read-only) once they have been uploaded, so a later
-        in-place edit of an array raises instead of leaving a stale copy on the GPU; replace the
-        DTree to change a stage."""
+        """The device-side cascade for the current stage list.  `classifier` and `theta` are plain public lists in the
+        reference and callers edit them -- and the trees' arrays -- in place, so the cached handle is keyed by the lists'
+        current CONTENT: the identity and the bytes of every tree (DTree.content: one private block per tree, joined in
+        one call) and the value and kind of every theta.  The GPU holds a private copy; nothing of the caller's is frozen."""
         # (theta by value AND kind: the float kind matters to theta_as_f32; a NaN theta still matches itself -- tuple
-        # comparison takes identical objects as equal -- and 128 reprs per call were a tenth of Model.detect's host time)
-        sig = (tuple(self.shape), tuple(map(id, self.classifier)), tuple(self.theta), tuple(map(type, self.theta)))
+        # comparison takes identical objects as equal)
+        ids = tuple(map(id, self.classifier))
+        cc = self._content
+        if cc is None or cc[0] != ids or cc[1] != _REBINDS[0]:
+            # (the trees' blocks as buffers, looked up once per stage list; a tree with a rebound array has no block and
+            # is read array by array on every call)
+            trees = list(self.classifier)                        # (keeps the ids alive and unique)
+            views = [memoryview(w._blob) for w in trees] if all(w._blob is not None for w in trees) else None
+            cc = self._content = (ids, _REBINDS[0], views, trees)
+        content = b"".join(cc[2]) if cc[2] is not None else b"".join([bytes(w.content()) for w in cc[3]])
+        sig = (tuple(self.shape), ids, tuple(self.theta), tuple(map(type, self.theta)), content)
         if self._device is None or self._device[0] != sig:
             dev = _engine.DeviceCascade(self.shape, self.classifier, self.theta)
-            for w in self.classifier:
-                for a in (w.feature, w.threshold, w.left, w.right, w.prediction):
-                    a.setflags(write=False)
             self._device = (sig, dev, list(self.classifier))     # (the list keeps the ids alive and unique)
         return self._device[1]
 
@@ -245,9 +250,7 @@ class Model:
         if getattr(images, "ndim", None) != 3 and (not hasattr(images, "dim") or images.dim() != 3):
             raise ValueError("images must have 3 dimensions [B,H,W]")
         B, H, W = (int(x) for x in images.shape)
-        dtype = images.dtype if isinstance(images, np.ndarray) else {"torch.uint8": np.uint8, "torch.float32": np.float32}.get(str(images.dtype))
-        if dtype is None:
-            raise NotImplementedError(f"image dtype {images.dtype} has no HIP kernel (uint8 and float32 are supported)")
+        dtype = _engine.array_dtype(images)
         shrink, n_per_oct, smooth, spec = _channels.read_opts(self.channel_opts)
         m, n, Cc = self.shape
         assert Cc == spec.n_channels, f"Invalid number of channels. Expected {Cc} given {spec.n_channels}."

@@ -11,19 +11,50 @@ from . import _native as nat
 from .compare import channel_tensor
 
 
+_ARRAYS = ("threshold", "prediction", "feature", "left", "right")
+_REBINDS = [0]          # bumped whenever an array attribute of any DTree is rebound (Model.device_cascade's cache watches it)
+
+
 class DTree:
     def __init__(self, feature, threshold, left, right, prediction):
-        # reference training.py:24-31
-        self.feature = np.array([f if f is not None else [0, 0, 0] for f in feature], np.uint8).reshape(-1, 3)
-        self.threshold = np.array(threshold, np.float32)
-        self.left = np.array(left, np.int8)
-        self.right = np.array(right, np.int8)
-        self.prediction = np.array(prediction, np.float32)
+        # reference training.py:24-31.  The five arrays are views into ONE private block of bytes per tree, so that
+        # `content()` -- what Model.device_cascade compares against the copy on the GPU -- is one buffer per tree;
+        # they stay writable (the reference's are) and an in-place edit shows up in that buffer.
+        feature = np.array([f if f is not None else [0, 0, 0] for f in feature], np.uint8).reshape(-1, 3)
+        threshold = np.array(threshold, np.float32)
+        left = np.array(left, np.int8)
+        right = np.array(right, np.int8)
+        prediction = np.array(prediction, np.float32)
+        k = left.size
+        if not (feature.shape[0] == threshold.size == right.size == prediction.size == k) or threshold.ndim != 1 \
+                or left.ndim != 1 or right.ndim != 1 or prediction.ndim != 1:
+            raise ValueError("DTree arrays must have one entry per node")
+        blob = np.empty(13 * k, np.uint8)
+        views = dict(threshold=blob[:4 * k].view(np.float32), prediction=blob[4 * k:8 * k].view(np.float32),
+                     feature=blob[8 * k:11 * k].reshape(k, 3), left=blob[11 * k:12 * k].view(np.int8),
+                     right=blob[12 * k:].view(np.int8))
+        for name, src in (("threshold", threshold), ("prediction", prediction), ("feature", feature), ("left", left),
+                          ("right", right)):
+            views[name][...] = src
+            object.__setattr__(self, name, views[name])
+        object.__setattr__(self, "_blob", blob)
         self.node = self.left >= 0
         self.node_idx = np.flatnonzero(self.node)
-        k = self.left.size
-        if not (self.feature.shape[0] == self.threshold.size == self.right.size == self.prediction.size == k):
-            raise ValueError("DTree arrays must have one entry per node")
+
+    def __setattr__(self, name, value):
+        # rebinding one of the arrays (w.threshold = other) detaches the tree from its block: content() then reads
+        # the five arrays one by one
+        if name in _ARRAYS:
+            object.__setattr__(self, "_blob", None)
+            _REBINDS[0] += 1
+        object.__setattr__(self, name, value)
+
+    def content(self):
+        """The tree's current arrays as one bytes-like object (cheap: the private block itself unless an array
+        was rebound)."""
+        if self._blob is not None:
+            return self._blob
+        return b"".join([np.ascontiguousarray(getattr(self, a)).tobytes() + b"|" for a in _ARRAYS])
 
     @staticmethod
     def fit(*args, **kwargs):
@@ -51,9 +82,10 @@ class DTree:
     # ---- evaluation
     def _device_arrays(self, dev):
         import torch
-        key = str(dev)
+        key = (str(dev), bytes(self.content()))          # (an edited tree is uploaded again)
         cache = self.__dict__.setdefault("_dev", {})
         if key not in cache:
+            cache.clear()
             cache[key] = tuple(torch.from_numpy(np.array(a)).to(dev) for a in
                                (self.feature, self.threshold, self.left, self.right, self.prediction))
         return cache[key]
