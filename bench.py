@@ -70,7 +70,8 @@ def cpu_baseline(model_path, images_per_core=6, max_cores=16):
 
 
 # ----------------------------------------------------------------------------- helpers
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIR = next((d for d in (os.path.join(ROOT, "profiles", r) for r in ("r03", "r02"))
+                    if os.path.exists(os.path.join(d, "sq_counters.json"))), os.path.join(ROOT, "profiles", "r02"))
 N_SIMD, CLOCK_GHZ = 256 * 4, 2.4          # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz max clock
 
 
@@ -99,14 +100,19 @@ def issue_bound(roof, batch, channels):
     fast = g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_FMA_F32")
     floor_us = (fast * 2.5 + (valu - fast) * 4.3) / (N_SIMD * CLOCK_GHZ * 1e3)
     wc = g("SQ_WAVE_CYCLES")
+    # straight from the counters, no model: the share of the CUs' busy time in which a SIMD's VALU pipe executes (both
+    # counters in quad-cycles per CU; 4 SIMDs per CU) and what one wave64 VALU instruction occupies it for
+    busy, act = g("SQ_BUSY_CU_CYCLES"), g("SQ_ACTIVE_INST_VALU")
+    valu_busy = act / busy if busy else None
+    cycles_per_valu = 4.0 * act / valu if valu else None
     wave_time = None
     if wc:
         wave_time = {"issuing": g("SQ_ACTIVE_INST_ANY") / wc, "waiting_for_issue_slot": g("SQ_WAIT_INST_ANY") / wc,
                      "waiting_on_data_or_barrier": g("SQ_WAIT_ANY") / wc}
     return {"kernel": roof["kernel"], "bound": "valu_issue", "valu_insts_per_launch": valu, "of_which_fp32_add_mul_fma": fast,
             "salu_insts_per_launch": salu, "floor_us": floor_us, "measured_us": roof["avg_launch_ms"] * 1e3,
-            "frac": floor_us / (roof["avg_launch_ms"] * 1e3), "wave_time": wave_time,
-            "counters": "profiles/r02/sq_counters.json",
+            "frac": floor_us / (roof["avg_launch_ms"] * 1e3), "valu_busy": valu_busy, "cycles_per_valu": cycles_per_valu,
+            "wave_time": wave_time, "counters": os.path.relpath(path, ROOT),
             "note": "2.5 issue cycles per wave64 fp32 add/mul/fma, 4.3 per other VALU instruction (measured classes); "
                     "1024 SIMDs at 2.4 GHz"}
 
@@ -458,8 +464,6 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 PMC passes (batch-1 launches only)
         traffic = None
         tpath = os.path.join(PROFILE_DIR, "traffic_pmc.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r01", "traffic_pmc.json")
         if os.path.exists(tpath) and B == 1 and args.channels == "grad_hist":
             with open(tpath) as f:
                 tj = json.load(f)
@@ -467,6 +471,11 @@ def main():
             traffic = tj.get(key, {}).get("traffic_bytes_per_launch_b1")
         roof = {"bound": "hbm", "kernel": "channels_kernel" if name == "channels_kernel" else "cascade_tile_kernel", "achieved": abytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                # what the hardware sees: the rank path writes one byte per channel value instead of SURVEY 8(d)'s float32
+                # and most source re-reads hit the caches, so the bytes MOVED are well below the algorithmic figure --
+                # frac is the contract's number, frac_moved the HBM utilisation (these kernels are VALU-issue-bound:
+                # see issue_bound.valu_busy)
+                "moved_bytes": traffic, "frac_moved": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": ms}
 
     # ---- the same workload through the reference's Python surface: host ndarray in, Boxes out (Model.detect,

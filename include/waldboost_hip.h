@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define WB_ABI_VERSION 4
+#define WB_ABI_VERSION 5
 
 #define WB_OK 0
 #define WB_ERR_INVALID (-1)     /* bad argument / malformed model */
@@ -161,8 +161,9 @@ typedef struct WbModelInfo {
 int wb_abi_version(void);
 const char *wb_last_error(void);
 
-/* Tile sizes of the channel kernel for a given shrink (outputs per workgroup). */
-int wb_channels_tile(int shrink, int *tile_u, int *tile_v);
+/* Tile sizes of the channel kernel (outputs per workgroup) for a channel function (WB_CHN_*) and shrink: what the
+ * tile table handed to wb_channels_launch must be cut to. */
+int wb_channels_tile(int channel_func, int shrink, int *tile_u, int *tile_v);
 
 /* Channel count and element dtype (WB_DTYPE_*) a channel function produces. */
 int wb_channel_func_info(int channel_func, int *n_channels, int *chn_dtype);

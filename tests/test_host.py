@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(nat.SYMBOLS), (declared ^ set(nat.SYMBOLS))
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.wb_abi_version() == nat.WB_ABI_VERSION == 4
+    assert lib.wb_abi_version() == nat.WB_ABI_VERSION == 5
     assert lib.wb_last_error() is not None
 
 
@@ -40,9 +40,11 @@ def test_channels_tile_query_and_argument_errors_without_gpu():
     import ctypes as C
     lib = nat.load()
     tu, tv = C.c_int(), C.c_int()
-    assert lib.wb_channels_tile(2, C.byref(tu), C.byref(tv)) == 0 and (tu.value, tv.value) == (16, 64)
-    assert lib.wb_channels_tile(4, C.byref(tu), C.byref(tv)) == 0 and (tu.value, tv.value) == (8, 32)
-    assert lib.wb_channels_tile(3, C.byref(tu), C.byref(tv)) == nat.WB_ERR_UNSUPPORTED
+    assert lib.wb_channels_tile(nat.WB_CHN_GRAD_HIST, 2, C.byref(tu), C.byref(tv)) == 0 and (tu.value, tv.value) == (16, 64)
+    assert lib.wb_channels_tile(nat.WB_CHN_GRAD_HIST_4_U1, 2, C.byref(tu), C.byref(tv)) == 0 and (tu.value, tv.value) == (16, 64)
+    assert lib.wb_channels_tile(nat.WB_CHN_GRAD_HIST, 1, C.byref(tu), C.byref(tv)) == 0 and (tu.value, tv.value) == (16, 64)
+    assert lib.wb_channels_tile(nat.WB_CHN_GRAD_HIST, 4, C.byref(tu), C.byref(tv)) == 0 and (tu.value, tv.value) == (8, 32)
+    assert lib.wb_channels_tile(nat.WB_CHN_GRAD_HIST, 3, C.byref(tu), C.byref(tv)) == nat.WB_ERR_UNSUPPORTED
     assert b"shrink=3" in lib.wb_last_error()
     # null pointers are rejected before any HIP call
     assert lib.wb_octaves_launch(None, None, 0, 1, 16, 16, 256, None, 0, None, 1, None) == nat.WB_ERR_INVALID

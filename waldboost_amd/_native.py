@@ -18,7 +18,7 @@ WB_DTYPE_F64, WB_DTYPE_I8, WB_DTYPE_I16, WB_DTYPE_U16, WB_DTYPE_I32, WB_DTYPE_U3
 WB_ERR_INVALID, WB_ERR_HIP, WB_ERR_UNSUPPORTED = -1, -2, -3
 WB_DET_SHARDS = 64
 WB_CHN_GRAD_HIST, WB_CHN_GRAD_HIST_4_U1, WB_CHN_GRAD_MAG_U1, WB_CHN_GRAD_MAG = 0, 1, 2, 3
-WB_ABI_VERSION = 4
+WB_ABI_VERSION = 5
 
 # numpy mirrors of the ABI structs (sizes asserted against the header's comments)
 LEVEL_DTYPE = np.dtype([
@@ -42,7 +42,7 @@ _P = C.c_void_p
 SYMBOLS = {
     "wb_abi_version": (C.c_int, []),
     "wb_last_error": (C.c_char_p, []),
-    "wb_channels_tile": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "wb_channels_tile": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "wb_channel_func_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "wb_octaves_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, C.c_int64,
                                     C.POINTER(C.c_int64), C.c_int, _P]),

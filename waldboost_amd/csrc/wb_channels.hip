@@ -257,9 +257,9 @@ __device__ inline void project_ordinary(float gx, float gy, const ChanArgs &, fl
     out[3] = fabsf(__builtin_fmaf(d3, kSinHi, d3 * kSinLo));
 }
 
-// Tile geometry shared by the channel kernels: TU x TV outputs per workgroup, shrink S
-template <int S_, int TU_, int TV_, bool SMOOTH_> struct TileGeom {
-    static constexpr int S = S_, TU = TU_, TV = TV_;
+// Tile geometry shared by the channel kernels: TU x TV outputs per workgroup of NT threads, shrink S
+template <int S_, int TU_, int TV_, bool SMOOTH_, int NT_ = 256> struct TileGeom {
+    static constexpr int S = S_, TU = TU_, TV = TV_, NT = NT_, NW = NT_ / 64;
     static constexpr bool SMOOTH = SMOOTH_;
     static constexpr int HS = SMOOTH ? 1 : 0;
     static constexpr int SU = TU + 2 * HS, SV = TV + 2 * HS;  // shrunk tile incl. smooth halo
@@ -271,7 +271,10 @@ template <int S_, int TU_, int TV_, bool SMOOTH_> struct TileGeom {
     // down-scaled levels of an octave that do not fit take the direct path
     // (shrink 2: 74 rows x 256 bytes instead of 80 x 236 -- the most down-scaled level of an octave of 8, zoom step
     // 1.834, needs 72 rows of 254 bytes and took the direct path before)
-    static constexpr int PROWS = S == 2 ? 74 : 2 * RH + 4, PPITCH = ((SU * SV * 16) / PROWS) & ~3;
+    // (32-row tiles: 70 resized rows at zoom step 1.834 tap 130 source rows)
+    static constexpr int PROWS = S == 2 ? (TU == 16 ? 74 : 2 * RH - 8) : 2 * RH + 4;
+    static constexpr int PPITCH = (S == 2 && TU != 16) ? 256 : ((SU * SV * 16) / PROWS) & ~3;
+    static_assert(PROWS * PPITCH <= SU * SV * 16, "the source patch shares the shrunk tile's memory");
     static constexpr int SH_BYTES = SU * SV * 16;
     static constexpr int PATCH_BYTES = PROWS * PPITCH;
 };
@@ -288,7 +291,7 @@ template <typename T, typename G>
 __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &L, const T *src, const double mn,
                                               const double mx, const int ry0, const int rx0, float *R,
                                               unsigned char *uni, float4 *rowtab, const int tid) {
-    constexpr int RH = G::RH, RW = G::RW, PROWS = G::PROWS, PPITCH = G::PPITCH;
+    constexpr int RH = G::RH, RW = G::RW, PROWS = G::PROWS, PPITCH = G::PPITCH, NT = G::NT, NW = G::NW;
     const Tap *__restrict__ rtap = a.taps + L.tap_off;      // row taps [nh], then column taps [nw]
     const Tap *__restrict__ ctap = rtap + L.nh;
     constexpr int NCS = RW / 64, MAINW = NCS * 64, LEFT = RW - MAINW;
@@ -306,12 +309,12 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
         if (ident && ry0 >= 0 && ry0 + RH <= L.nh && rx0 >= 0 && rx0 + 4 * RWD <= L.nw) {
             static_assert(RW % 2 == 0, "pixel pairs");
             typedef uint32_t __attribute__((aligned(1))) u32u;
-            constexpr int NE = RH * RWD, PER = (NE + 255) / 256;
+            constexpr int NE = RH * RWD, PER = (NE + NT - 1) / NT;
             uint32_t v[PER];
             int at[PER];
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                int e = tid + 256 * i;
+                int e = tid + NT * i;
                 e = e < NE ? e : NE - 1;                              // (duplicates rewrite the same values)
                 const int k = e / RWD, d = e - k * RWD;
                 v[i] = *reinterpret_cast<const u32u *>(src + (int64_t)(ry0 + k) * L.src_w + rx0 + 4 * d);
@@ -358,7 +361,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
         const int nrow = r_hi - r_lo + 1, nbyte = c_hi - c_lo + 1;
         staged = strict && nrow + 1 <= PROWS && nbyte + 8 <= PPITCH;
         WB_CSTAMP(1);
-        // the taps the resample below wants -- a lane's column taps, the tile's row taps (lane l: row l), the taps of the
+        // the taps the resample below wants -- a lane's column taps, the row taps of the wave's strip (lane l: its row l), the taps of the
         // RW % 64 right-most columns -- are requested HERE, in front of the patch loads: behind the staging barrier each
         // of these loads was one more exposed memory round trip per workgroup
 #pragma unroll
@@ -368,7 +371,10 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             tcs[c] = ctap[x];
         }
         {
-            int ly = ry0 + (lane < RH ? lane : RH - 1);
+            constexpr int RS = (RH + NW - 1) / NW;              // rows of a wave's strip (see the row loop)
+            static_assert(RS <= 64, "one lane per row of the strip");
+            const int kl = wave * RS + lane;
+            int ly = ry0 + (kl < RH ? kl : RH - 1);
             ly = ly < 0 ? 0 : (ly > L.nh - 1 ? L.nh - 1 : ly);
             trl = rtap[ly];
             int lx = rx0 + MAINW + (lane < LEFT ? lane : 0);
@@ -390,12 +396,12 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                 int dw = dw0 + ln;
                 dw = dw < ndw ? dw : ndw - 1;
                 const T *col = src + c_lo + 4 * dw;
-                for (int r0 = wv; r0 < nrow; r0 += 4 * UR) {
+                for (int r0 = wv; r0 < nrow; r0 += NW * UR) {
                     uint32_t v[UR];
                     int rr[UR];
 #pragma unroll
                     for (int k = 0; k < UR; ++k) {
-                        rr[k] = r0 + 4 * k < nrow ? r0 + 4 * k : nrow - 1;
+                        rr[k] = r0 + NW * k < nrow ? r0 + NW * k : nrow - 1;
                         v[k] = *reinterpret_cast<const u32u *>(col + (int64_t)(r_lo + rr[k]) * L.src_w);
                     }
 #pragma unroll
@@ -406,7 +412,11 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             // Read back below with one wave-uniform (broadcast) LDS load per row: the values arrive in VECTOR registers
             // -- on gfx950 an fp32 add / multiply / fmac whose operands are all vector registers issues in 2 cycles,
             // with a scalar-register operand in 4 (tools/valu_class_probe.hip), and a v_readlane costs 4 as well
-            if (tid < RH) rowtab[tid] = make_float4(__int_as_float((trl.i0 - r_lo) * PPITCH), (float)trl.w0, (float)trl.w1, 0.0f);
+            {
+                constexpr int RS = (RH + NW - 1) / NW;
+                const int kl = wave * RS + lane;
+                if (lane < RS && kl < RH) rowtab[kl] = make_float4(__int_as_float((trl.i0 - r_lo) * PPITCH), (float)trl.w0, (float)trl.w1, 0.0f);
+            }
             if (LEFT > 0 && tid >= 64 && tid < 64 + LEFT)
                 rowtab[RH + tid - 64] = make_float4(__int_as_float(tleft.i0 - c_lo), (float)tleft.w0, (float)tleft.w1, 0.0f);
             __syncthreads();
@@ -425,8 +435,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                 wc0f[c] = (float)tc[c].w0;
                 wc1f[c] = (float)tc[c].w1;
             }
-            // (fp64 row taps for the exact redo: lane l holds those of tile row l -- trl -- fetched by readlane there)
-            static_assert(RH <= 64, "one lane per tile row");
+            // (fp64 row taps for the exact redo: lane l holds those of row l of the wave's strip -- trl -- fetched by readlane there)
             // Each wave owns a strip of consecutive tile rows and walks it two rows per pass: every tap byte of
             // the pass is requested before the first is used, and the rare exact redo is deferred behind all the
             // fast-path arithmetic (one branch per pass; which pixels want it is kept as lane masks).  Consecutive
@@ -437,7 +446,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
 #define WB_CHAN_RB 2
 #endif
             constexpr int RB = WB_CHAN_RB;
-            constexpr int RS = (RH + 3) / 4;
+            constexpr int RS = (RH + NW - 1) / NW;
             const int k_lo = wave * RS, k_hi = k_lo + RS < RH ? k_lo + RS : RH;
             float hprev[NCS];                     // horizontal interpolation of the patch row at byte offset o_prev,
             uint8_t pb[NCS][2];                   // and its two tap bytes (the exact redo wants them)
@@ -521,8 +530,8 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                         // from the tap table here stalled the whole pass behind an L2 round trip)
                         Tap tr;
                         tr.i0 = tr.i1 = 0;
-                        tr.w0 = lane_f64(trl.w0, k);
-                        tr.w1 = lane_f64(trl.w1, k);
+                        tr.w0 = lane_f64(trl.w0, k - k_lo);
+                        tr.w1 = lane_f64(trl.w1, k - k_lo);
 #pragma unroll
                         for (int c = 0; c < NCS; ++c) {
                             if (need[rb][c])
@@ -557,12 +566,12 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
         // RB rows per pass: all their source loads are in flight before the first one is used
         // (one row at a time, the loop was a chain of RH/4 memory latencies per wave)
         constexpr int RB = sizeof(T) == 8 ? 2 : 5;             // (a double pixel is two registers)
-        for (int k0 = wave; k0 < RH; k0 += 4 * RB) {
+        for (int k0 = wave; k0 < RH; k0 += NW * RB) {
             Tap tr[RB];
             T v00[RB][NCS], v01[RB][NCS], v10[RB][NCS], v11[RB][NCS];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                int k = k0 + 4 * rb;
+                int k = k0 + NW * rb;
                 k = k < RH ? k : RH - 1;                                  // clamped, unconditional loads
                 int y = ry0 + k;
                 y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
@@ -579,7 +588,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             }
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                const int k = k0 + 4 * rb;
+                const int k = k0 + NW * rb;
 #pragma unroll
                 for (int c = 0; c < NCS; ++c) {
                     float out = 0.0f;
@@ -601,7 +610,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
     }
     WB_CSTAMP(3);
     if constexpr (LEFT > 0) {
-        for (int p = tid; p < RH * LEFT; p += 256) {
+        for (int p = tid; p < RH * LEFT; p += NT) {
             const int k = p / LEFT, q = MAINW + p - k * LEFT;
             int y = ry0 + k, x = rx0 + q;
             y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
@@ -641,9 +650,10 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
 
 // (launch bound: 4 workgroups = 4 waves per SIMD is what the 39 KB of LDS admit; without it the register
 // allocator may trade that occupancy for a few more registers -- measured: 138 VGPRs, 3 waves per SIMD, +17 % time)
-template <typename T, int S, int TU, int TV, bool SMOOTH, bool FAST>
-__global__ __launch_bounds__(256, sizeof(T) == 8 || S == 4 ? 1 : 4) void channels_kernel(ChanArgs a) {
-    using G = TileGeom<S, TU, TV, SMOOTH>;
+// (NT threads per workgroup: 256 for the 16 x 64 tile, 512 for the 32 x 64 tile -- the same 4 waves per SIMD either way)
+template <typename T, int S, int TU, int TV, bool SMOOTH, bool FAST, int NT>
+__global__ __launch_bounds__(NT, sizeof(T) == 8 || S == 4 ? 1 : 4) void channels_kernel(ChanArgs a) {
+    using G = TileGeom<S, TU, TV, SMOOTH, NT>;
     constexpr int HS = G::HS, SU = G::SU, SV = G::SV, RH = G::RH, RW = G::RW, P = G::P;
     constexpr int PATCH_BYTES = sizeof(T) == 1 ? G::PATCH_BYTES : 0;
     constexpr int UNI_BYTES = G::SH_BYTES > PATCH_BYTES ? G::SH_BYTES : PATCH_BYTES;
@@ -675,7 +685,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 || S == 4 ? 1 : 4) void channel
     if (a.dbg & 1) return;
 
     // ---- step 2: gradients -> 4 oriented channels -> shrink, one shrunk pixel per iteration
-    for (int p = tid; p < SU * SV; p += 256) {
+    for (int p = tid; p < SU * SV; p += NT) {
         int i = p / SV, j = p - i * SV;
         float pt[P][P];
 #pragma unroll
@@ -760,22 +770,21 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 || S == 4 ? 1 : 4) void channel
     }
     // rank tables of the model (12 KiB, L2-resident): requested before the barrier, parked in R -- dead once every
     // thread has left step 2 -- right behind it
-    constexpr int LUT_PER_THREAD = WB_BIN_LUT_BYTES / 16 / 256;
-    static_assert(WB_BIN_LUT_BYTES % (16 * 256) == 0, "whole 16-byte vectors per thread");
+    constexpr int LUT_VECS = WB_BIN_LUT_BYTES / 16;
+    static_assert(LUT_VECS == 768 && (NT == 256 || NT == 512), "three vectors per thread (256 threads), one or two (512)");
     const bool ranks = a.rank != nullptr;
-    static_assert(LUT_PER_THREAD == 3, "three vectors per thread below");
     uint4 lut0 = make_uint4(0, 0, 0, 0), lut1 = lut0, lut2 = lut0;
     if (ranks) {
         lut0 = a.rank_lut[tid];
-        lut1 = a.rank_lut[tid + 256];
-        lut2 = a.rank_lut[tid + 512];
+        if (NT == 256 || tid < 256) lut1 = a.rank_lut[tid + NT];
+        if (NT == 256) lut2 = a.rank_lut[tid + 512];
     }
     __syncthreads();
     if (ranks) {
         uint4 *lut = reinterpret_cast<uint4 *>(R);
         lut[tid] = lut0;
-        lut[tid + 256] = lut1;
-        lut[tid + 512] = lut2;
+        if (NT == 256 || tid < 256) lut[tid + NT] = lut1;
+        if (NT == 256) lut[tid + 512] = lut2;
     }
     WB_CSTAMP(5);
 
@@ -783,8 +792,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 8 || S == 4 ? 1 : 4) void channel
     // ---- step 3: 3x3 binomial smooth (fp64 sum in source order, /16, one rounding), border = 0.
     //      Each thread owns RPT vertically adjacent outputs of one column, so every shrunk value
     //      it needs is read and widened to fp64 once for up to three output rows.
-    constexpr int RPT = TU * TV / 256;
-    static_assert(TU * TV % 256 == 0 && 256 % TV == 0, "tile must split into whole thread strips");
+    constexpr int RPT = TU * TV / NT;
+    static_assert(TU * TV % NT == 0 && NT % TV == 0, "tile must split into whole thread strips");
     float *out = reinterpret_cast<float *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
     const int j = tid % TV, i0 = (tid / TV) * RPT;
     const int sv = v0 + j;
@@ -1047,22 +1056,27 @@ __global__ void selftest_projection_kernel(ChanArgs a, uint32_t *mismatches) {
         if (__float_as_uint(f[k]) != __float_as_uint(r[k])) atomicAdd(mismatches, 1u);
 }
 
-template <typename T, int S, int TU, int TV, bool FAST>
+template <typename T, int S, int TU, int TV, bool FAST, int NT = 256>
 void launch_variant(hipStream_t st, dim3 grid, const ChanArgs &a, bool smooth) {
     // diagnostic (WB_CHAN_XLDS=bytes): extra dynamic LDS per workgroup lowers the workgroups per CU, to tell a
     // latency-bound kernel (time ~ 1 / residency) from a throughput-bound one (time unchanged)
     static const size_t xlds = getenv("WB_CHAN_XLDS") ? (size_t)atoi(getenv("WB_CHAN_XLDS")) : 0;
     if (smooth)
-        hipLaunchKernelGGL((channels_kernel<T, S, TU, TV, true, FAST>), grid, dim3(256), xlds, st, a);
+        hipLaunchKernelGGL((channels_kernel<T, S, TU, TV, true, FAST, NT>), grid, dim3(NT), xlds, st, a);
     else
-        hipLaunchKernelGGL((channels_kernel<T, S, TU, TV, false, FAST>), grid, dim3(256), xlds, st, a);
+        hipLaunchKernelGGL((channels_kernel<T, S, TU, TV, false, FAST, NT>), grid, dim3(NT), xlds, st, a);
 }
 
 template <typename T, bool FAST>
-int launch_dtype(hipStream_t st, dim3 grid, const ChanArgs &a, int shrink, bool smooth) {
+int launch_dtype(hipStream_t st, dim3 grid, const ChanArgs &a, int shrink, bool smooth, bool tile32) {
     switch (shrink) {
         case 1: launch_variant<T, 1, 16, 64, FAST>(st, grid, a, smooth); break;
-        case 2: launch_variant<T, 2, 16, 64, FAST>(st, grid, a, smooth); break;
+        case 2:
+            if (tile32)
+                launch_variant<T, 2, 32, 64, FAST, 512>(st, grid, a, smooth);
+            else
+                launch_variant<T, 2, 16, 64, FAST>(st, grid, a, smooth);
+            break;
         case 4: launch_variant<T, 4, 8, 32, FAST>(st, grid, a, smooth); break;
         default:
             wb_set_error("wb_channels_launch: shrink=%d unsupported (1, 2; 4 as an extension)", shrink);
@@ -1268,6 +1282,15 @@ int launch_u1(hipStream_t st, dim3 grid, const ChanArgs &a, int shrink, bool smo
     return WB_OK;
 }
 
+// experiment (WB_CHAN_TILE32=1): grad_hist at shrink 2 on a 32 x 64 tile of 512 threads -- 14 % of the resized pixels a
+// workgroup computes are halo instead of 24 %, 5 % fewer vector instructions per image, and yet 39.6 against 33.0 us
+// per image at batch 64 (47.3 -> 51.5 at batch 1): two workgroups of eight waves per CU overlap their load and
+// compute phases worse than four of four.  Kept for A/B runs; the default is the 16 x 64 tile.
+bool tile32() {
+    static const bool t32 = getenv("WB_CHAN_TILE32") != nullptr;
+    return t32;
+}
+
 // the canonical constants np.cos/np.sin(np.linspace(0, pi, 5)[:-1]) the integer fast path is proven for
 const double kCanonCs[4] = {1.0, 0x1.6a09e667f3bcdp-1, 0x1.1a62633145c07p-54, -0x1.6a09e667f3bccp-1};
 const double kCanonSn[4] = {0.0, 0x1.6a09e667f3bccp-1, 1.0, 0x1.6a09e667f3bcdp-1};
@@ -1291,10 +1314,12 @@ void set_constants(ChanArgs &a, const double *cs_sn) {
 
 }  // namespace
 
-extern "C" int wb_channels_tile(int shrink, int *tile_u, int *tile_v) {
+extern "C" int wb_channels_tile(int channel_func, int shrink, int *tile_u, int *tile_v) {
     WB_REQUIRE(tile_u && tile_v, "wb_channels_tile: null pointer");
     if (shrink == 1 || shrink == 2) {
-        *tile_u = 16;
+        // (see tile32(): the 32 x 64 tile of 512 threads is an opt-in experiment)
+        const bool big = shrink == 2 && channel_func == WB_CHN_GRAD_HIST && tile32();
+        *tile_u = big ? 32 : 16;
         *tile_v = 64;
     } else if (shrink == 4) {
         *tile_u = 8;
@@ -1388,13 +1413,13 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
     if (dtype == WB_DTYPE_U8) {
         // integer gradients + canonical constants: exact fp32 projection (see project_int)
         static const bool no_fast = getenv("WB_CHAN_NO_FAST") != nullptr;
-        if (canonical_constants(cs_sn) && !no_fast) return launch_dtype<uint8_t, true>(st, grid, a, shrink, smooth != 0);
-        return launch_dtype<uint8_t, false>(st, grid, a, shrink, smooth != 0);
+        if (canonical_constants(cs_sn) && !no_fast) return launch_dtype<uint8_t, true>(st, grid, a, shrink, smooth != 0, tile32());
+        return launch_dtype<uint8_t, false>(st, grid, a, shrink, smooth != 0, tile32());
     }
-    if (dtype == WB_DTYPE_F32) return launch_dtype<float, false>(st, grid, a, shrink, smooth != 0);
+    if (dtype == WB_DTYPE_F32) return launch_dtype<float, false>(st, grid, a, shrink, smooth != 0, tile32());
     if (dtype == WB_DTYPE_F64 || (dtype >= WB_DTYPE_I8 && dtype <= WB_DTYPE_U32)) {
         a.src_int = dtype != WB_DTYPE_F64;
-        return launch_dtype<double, false>(st, grid, a, shrink, smooth != 0);
+        return launch_dtype<double, false>(st, grid, a, shrink, smooth != 0, tile32());
     }
     wb_set_error("wb_channels_launch: unsupported image dtype code %d", dtype);
     return WB_ERR_UNSUPPORTED;

@@ -214,7 +214,7 @@ class PyramidEngine:
         self.wide_keys = self.store_dtype == np.float64                # 64-bit (min, max) keys per octave
         self.batch = int(batch)
         self.plan = PyramidPlan(H, W, shrink, n_per_oct, smooth, exact_single=exact_single,
-                                n_chn=self.spec.n_channels, chn_bytes=self.spec.dtype.itemsize)
+                                n_chn=self.spec.n_channels, chn_bytes=self.spec.dtype.itemsize, chan_func=self.spec.func_id)
         self.exact_single = exact_single
         p = self.plan
         dev = self.dev

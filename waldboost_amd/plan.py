@@ -19,7 +19,16 @@ import numpy as np
 from ._native import LEVEL_DTYPE, TAP_DTYPE, TILE_DTYPE
 
 N_CHANNELS = 4          # grad_hist with n_bins=4 (reference channels.py:40): the default channel function
-CHAN_TILES = {1: (16, 64), 2: (16, 64), 4: (8, 32)}   # must match wb_channels_tile()
+
+
+def chan_tile(chan_func, shrink):
+    """(tile_u, tile_v) outputs per workgroup of the channel kernel for a channel function (WB_CHN_*) and shrink:
+    asked of the library (wb_channels_tile) -- the kernel's compile-time geometry is the only authority."""
+    import ctypes as C
+    from . import _native as nat
+    tu, tv = C.c_int(), C.c_int()
+    nat.check(nat.load().wb_channels_tile(int(chan_func), int(shrink), C.byref(tu), C.byref(tv)), "wb_channels_tile")
+    return tu.value, tv.value
 
 
 def octave_shapes(H, W):
@@ -43,11 +52,12 @@ def xcd_order(n):
 
 
 class PyramidPlan:
-    def __init__(self, H, W, shrink, n_per_oct, smooth=1, exact_single=False, n_chn=N_CHANNELS, chn_bytes=4):
+    def __init__(self, H, W, shrink, n_per_oct, smooth=1, exact_single=False, n_chn=N_CHANNELS, chn_bytes=4, chan_func=0):
         assert shrink in (1, 2, 4), "Shrink factor must be 1 or 2 (4 is a documented extension)"
         self.H, self.W = int(H), int(W)
         self.shrink, self.n_per_oct, self.smooth = int(shrink), int(n_per_oct), int(smooth)
         self.n_chn, self.chn_bytes = int(n_chn), int(chn_bytes)     # channels per pixel, bytes per channel value
+        self.chan_func = int(chan_func)                              # WB_CHN_* (0 = grad_hist): selects the channel kernel's tile
         # exact_single: one level at the image's own size, whatever that size is
         self.octaves = [(self.H, self.W)] if exact_single else octave_shapes(H, W)
         self.n_oct = len(self.octaves)
@@ -169,7 +179,7 @@ class PyramidPlan:
 
     def chan_tiles(self):
         if self._chan_tiles is None:
-            tu, tv = CHAN_TILES[self.shrink]
+            tu, tv = chan_tile(self.chan_func, self.shrink)
             self._chan_tiles = self._tiles([(lv["u"], lv["v"]) for lv in self.levels], tu, tv)
         return self._chan_tiles
 
