@@ -178,6 +178,7 @@ def main():
                          "and the staggered start of the streams (K=20: +5 %%), a long one amortises both")
     ap.add_argument("--only", choices=["all", "channels", "cascade", "octaves"], default="all",
                     help="profile helper: launch only one kernel group in the timed loop")
+    ap.add_argument("--no-jit", action="store_true", help="stay on the generic cascade kernel (stage records through the scalar cache)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the ranks, rendezvous (gloo on the CPU), let rank 0 print what it would run, stop: checks "
                          "the launch path on a machine without GPUs")
@@ -239,6 +240,13 @@ def main():
     if args.stages:
         M.classifier, M.theta = M.classifier[:args.stages], M.theta[:args.stages]
     dm = M.device_cascade()
+    # the model-specialised cascade kernel (hiprtc, the stage records as constants): built up front, outside every
+    # timed region -- what a caller of Model.detect gets by itself after a few scans (engine.py: _JIT_AFTER)
+    jit = False
+    if os.environ.get("WB_CASC_JIT", "1") != "0" and not args.no_jit:
+        t_jit = time.perf_counter()
+        jit = bool(dm.specialize())
+        t_jit = time.perf_counter() - t_jit
     B, P = args.batch, max(1, args.pool)
     engines = []
     for i in range(P):
@@ -512,6 +520,7 @@ def main():
                                                                 else "hipGraph replay per step"), "only": args.only,
                        "channels_in_hbm": "uint8 threshold ranks of the cascade (WB_DTYPE_RANK8)" if fused else spec.dtype.name,
                        "streams": n_streams, "pool": P,
+                       "cascade_kernel": (f"model-specialised (hiprtc at model load, {t_jit:.1f} s incl. cache lookup)" if jit else "generic"),
                        "collective": "one all_gather of the P packed detection prefixes per round of P steps (side stream)" if coll else "none"},
             "mpixels_per_s": world * args.steps * B * H * W / dt / 1e6,
             "images_per_s": world * args.steps * B / dt,

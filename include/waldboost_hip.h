@@ -156,6 +156,7 @@ typedef struct WbModelInfo {
     int32_t tile_cols;
     int32_t lds_bytes;  /* dynamic LDS per workgroup of the cascade kernel         */
     int32_t rank_ok;    /* 1 = the model has rank tables (WB_DTYPE_RANK8 channels)  */
+    int32_t specialized; /* bit 0: a model-specialised kernel is loaded for uint8 channels, bit 1: for ranks */
 } WbModelInfo;
 
 int wb_abi_version(void);
@@ -231,6 +232,18 @@ int wb_model_create(int n_stages, const int32_t *node_off, const uint8_t *featur
                     WbModel **out);
 int wb_model_destroy(WbModel *model);
 int wb_model_info(const WbModel *model, WbModelInfo *info);
+
+/* Compile (hiprtc, a couple of seconds the first time; afterwards from the cache directory $WB_JIT_CACHE, default
+ * ~/.cache/waldboost_amd) and load the model-specialised tile kernel for one kind of byte tile: chn_dtype
+ * WB_DTYPE_RANK8 or WB_DTYPE_U8.  The model's stage records -- feature offsets, thresholds (model.py:62-67,
+ * training.py:24-31), leaf values and theta -- are compile-time constants in it.  wb_cascade_launch uses it from then
+ * on for that dtype; results are bit-identical to the generic kernel's.  WB_ERR_UNSUPPORTED for float32 channels and
+ * for models on the node-walk kernel; a failed compilation leaves the model on the generic kernel. */
+int wb_model_specialize(WbModel *model, int chn_dtype);
+
+/* Build check of the specialised kernel's source without a GPU: a synthetic cascade of n_stages depth-`depth` trees
+ * through the generator and hiprtc for `arch` (e.g. "gfx950"); *code_bytes = size of the code object. */
+int wb_jit_compile_check(int depth, int n_stages, const char *arch, int64_t *code_bytes);
 
 /* Dense sliding-window cascade over all levels of all images.
  *   chn           [u][v][C] per level as written by wb_channels_launch (or caller-provided), of

@@ -1,0 +1,111 @@
+"""The model-specialised cascade kernel (csrc/wb_jit.hip: hiprtc, the model's stage records as compile-time constants)
+against the generic kernel and the oracle: indices, alive[level, stage], score bits and boxes must be identical --
+reference model.py:216-259, training.py:84-96."""
+import os
+
+import numpy as np
+import pytest
+
+import waldboost_amd as wb
+from waldboost_amd import _native as nat
+from waldboost_amd.synth import random_tree_arrays, synth_image
+from util import GOLDEN, oracle_detect
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_same(res, ref):
+    assert np.array_equal(res["alive"], ref["alive"])
+    assert np.array_equal(res["level"], ref["level"]) and np.array_equal(res["r"], ref["r"]) and np.array_equal(res["c"], ref["c"])
+    assert np.array_equal(bits(res["scores"]), bits(ref["scores"])) and np.array_equal(bits(res["boxes"]), bits(ref["boxes"]))
+
+
+def both_kernels(M, img):
+    """detect_raw on the generic kernel, then on the specialised one; both against the oracle.  Returns the oracle's dict."""
+    ref = oracle_detect(M, img)
+    dm = M.device_cascade()
+    assert not dm.specialized()
+    assert_same(M.detect_raw(img), ref)                     # generic kernel (first scan)
+    assert dm.specialize()
+    kind = nat.WB_DTYPE_RANK8 if dm.rank_ok else nat.WB_DTYPE_U8
+    assert kind in dm.specialized()
+    for _ in range(2):                                      # eager, then the captured graph of Model.detect
+        assert_same(M.detect_raw(img), ref)
+    return ref
+
+
+@pytest.mark.parametrize("path,shape", [("models/cfg2_d2_T128.pb", (1080, 1920)), ("mixed_d2_T24.pb", (240, 320)),
+                                        ("cfg1_d1_T32.pb", (480, 640)), ("models/cfg2_gh4u1_d2_T128.pb", (540, 960)),
+                                        ("grad_hist_4_u1_d2_T24.pb", (200, 264)), ("grad_mag_u1_d2_T24.pb", (200, 264))])
+def test_specialised_kernel_equals_generic_and_oracle_on_the_committed_models(path, shape):
+    M = wb.load(os.path.join(GOLDEN, path))
+    ref = both_kernels(M, synth_image(*shape, 11))
+    assert ref["scores"].size > 0
+
+
+def random_model(seed, T, depth_of, C=4, func=None, lo=2.0, hi=60.0, theta_inf=0.2, shape=(12, 12)):
+    rng = np.random.default_rng(seed)
+    opts = dict(wb.default_channel_opts)
+    if func is not None:
+        opts["channels"] = func
+    M = wb.Model((*shape, C), opts)
+    acc, step = 0.0, float(rng.uniform(-0.4, 0.0))
+    for t in range(T):
+        d = depth_of(rng)
+        f, th, l, r, p = random_tree_arrays(rng, (*shape, C), d, lo, hi, unbalanced=(d == 2 and rng.random() < 0.3))
+        acc += step
+        M.append(wb.DTree(f, th, l, r, p), float("-inf") if rng.random() < theta_inf else float(np.float32(acc)))
+    return M
+
+
+@pytest.mark.parametrize("seed,T,depth", [(0, 1, 2), (1, 5, 2), (2, 8, 1), (3, 9, 2), (4, 13, 3), (5, 16, 2), (6, 17, 1), (7, 31, 2),
+                                          (8, 40, 3), (9, 70, 2), (10, 130, 2), (11, 200, 1), (12, 330, 2)])
+def test_specialised_kernel_on_random_cascades_of_every_length_and_depth(seed, T, depth):
+    """Phase A shorter than its 8 stages, lengths off the group size, every depth the tile kernel takes (1-3), segment
+    chains up to 330 stages, never-rejecting stages: rank tiles (grad_hist) and uint8 channel tiles alternate."""
+    u1 = seed % 2 == 1
+    M = random_model(100 + seed, T, lambda rng: depth if depth < 3 else int(rng.integers(1, 4)),
+                     func=wb.channels.SPECS["grad_hist_4_u1"].func if u1 else None, lo=0.5 if u1 else 2.0, hi=20.0 if u1 else 60.0)
+    img = synth_image(150 + 13 * seed, 210 + 7 * seed, seed)
+    both_kernels(M, img)
+
+
+def test_specialised_kernel_with_special_thresholds_and_leaf_values():
+    """NaN / negative / infinite thresholds (rank -1 and always-left nodes), infinite and signed-zero leaf values: the
+    specialised stages take them from literals and from the LDS mirror -- same bits as the generic walk."""
+    M = random_model(7, 24, lambda rng: 2)
+    specials = [np.nan, -1.0, np.inf, -np.inf, 0.0, -0.0]
+    for i, (w, _) in enumerate(M):
+        w.threshold[i % w.threshold.size] = specials[i % len(specials)]
+        if i % 5 == 0:
+            w.prediction[-1] = [np.inf, -0.0, 1e-30][i // 5 % 3]
+    M.theta[3] = float("-inf")
+    both_kernels(M, synth_image(200, 264, 5))
+
+
+def test_auto_specialisation_after_a_few_scans_and_models_it_cannot_take():
+    from waldboost_amd import engine
+    M = wb.load(os.path.join(GOLDEN, "mixed_d2_T24.pb"))
+    img = synth_image(200, 264, 2)
+    ref = oracle_detect(M, img)
+    dm = M.device_cascade()
+    for i in range(3):       # Model.detect: the second call builds the specialised kernel, then captures its graph with it
+        assert_same(M.detect_raw(img), ref)
+        assert bool(dm.specialized()) == (i >= 1 and engine._JIT_AUTO)
+    M2 = wb.load(os.path.join(GOLDEN, "grad_hist_4_u1_d2_T24.pb"))      # engine-level scans: after _JIT_AFTER of them
+    e = engine.PyramidEngine(200, 264, np.uint8, 2, 8, 1, channels=wb.channels.channel_spec(M2.channel_opts["channels"]))
+    e.load_images(img)
+    dm2 = M2.device_cascade()
+    for i in range(engine._JIT_AFTER + 1):
+        e.run(dm2)
+        assert bool(dm2.specialized()) == (i + 1 >= engine._JIT_AFTER and engine._JIT_AUTO)
+    # a cascade of trees deeper than the tile kernel walks runs on the node-walk kernel: nothing to specialise
+    deep = random_model(3, 6, lambda rng: 5)
+    assert deep.device_cascade().specialize() is False
+    assert_same(deep.detect_raw(img), oracle_detect(deep, img))
+    # float32 channel tiles have no specialised kernel
+    assert dm.specialize(nat.WB_DTYPE_F32) is False

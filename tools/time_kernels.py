@@ -11,6 +11,8 @@ from waldboost_amd.synth import synth_image
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 M = wb.load(os.path.join(ROOT, "tests/golden/models/cfg2_d2_T128.pb"))
 dm = M.device_cascade()
+if os.environ.get("WB_CASC_JIT", "1") != "0":
+    print("specialised:", dm.specialize())
 e = PyramidEngine(1080, 1920, np.uint8, 2, 8, 1, batch=B, det_capacity=16384 * B)
 e.load_images(np.stack([synth_image(1080, 1920, s) for s in range(B)]))
 e.run(dm); torch.cuda.synchronize()

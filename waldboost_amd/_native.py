@@ -34,7 +34,7 @@ assert LEVEL_DTYPE.itemsize == 64 and TILE_DTYPE.itemsize == 8 and DET_DTYPE.ite
 class WbModelInfo(C.Structure):
     _fields_ = [("n_stages", C.c_int32), ("depth", C.c_int32), ("m", C.c_int32), ("n", C.c_int32),
                 ("C", C.c_int32), ("tile_rows", C.c_int32), ("tile_cols", C.c_int32), ("lds_bytes", C.c_int32),
-                ("rank_ok", C.c_int32)]
+                ("rank_ok", C.c_int32), ("specialized", C.c_int32)]
 
 
 # every symbol include/waldboost_hip.h declares: name -> (restype, argtypes)
@@ -54,6 +54,8 @@ SYMBOLS = {
     "wb_model_create": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "wb_model_destroy": (C.c_int, [_P]),
     "wb_model_info": (C.c_int, [_P, C.POINTER(WbModelInfo)]),
+    "wb_model_specialize": (C.c_int, [_P, C.c_int]),
+    "wb_jit_compile_check": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int64)]),
     "wb_cascade_launch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P,
                                     C.c_uint32, _P]),
     "wb_tree_eval_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P, _P, _P, _P, _P,

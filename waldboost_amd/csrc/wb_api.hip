@@ -11,6 +11,8 @@
 
 int wb_cascade_prepare(int depth, int rpw, int waves);  // wb_cascade.hip
 int wb_cascade_group(int depth);                        // stages evaluated per group
+int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch,
+               void **func_out);   // wb_jit.hip
 
 static thread_local char g_err[512] = "";
 
@@ -148,10 +150,11 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         M->tile_rows = rpw * waves;
         M->lds_rows = M->tile_rows + m - 1;
         M->lds_stages = (n_stages * WB_STAGE_DWORDS(D) * 4 <= 16 * 1024) ? n_stages : 0;
+        // (layout: wb_cascade_tile.h, wb_lds_stab_off; 128 bytes of control words behind the stage mirror)
         M->lds_bytes = ((C * M->lds_rows * M->lds_pitch * 4 + M->tile_rows * WB_CASC_TC * 8 + n_stages * 4 + 15) & ~15) +
-                       M->lds_stages * WB_STAGE_DWORDS(D) * 4;
+                       M->lds_stages * WB_STAGE_DWORDS(D) * 4 + 128;
         M->lds_bytes_u8 = ((((C * M->lds_rows * M->lds_pitch + 15) & ~15) + M->tile_rows * WB_CASC_TC * 8 + n_stages * 4 + 15) & ~15) +
-                          M->lds_stages * WB_STAGE_DWORDS(D) * 4;
+                          M->lds_stages * WB_STAGE_DWORDS(D) * 4 + 128;
         if (M->lds_bytes <= budget || rpw <= 1) break;
     }
     if (!generic && M->lds_bytes > 160 * 1024) {
@@ -297,6 +300,13 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
             fclose(f);
         }
     }
+    M->stage_words = packs[1].size();
+    M->stages_u8_host = static_cast<int32_t *>(malloc(packs[1].size() * 4 + 4));
+    memcpy(M->stages_u8_host, packs[1].data(), packs[1].size() * 4);
+    if (M->bin_ok) {
+        M->stages_bin_host = static_cast<int32_t *>(malloc(packs[2].size() * 4 + 4));
+        memcpy(M->stages_bin_host, packs[2].data(), packs[2].size() * 4);
+    }
     {
         const std::vector<int32_t> &packed = packs[0];
         hipError_t e = hipMalloc((void **)&M->stages_dev, packed.size() * 4);
@@ -330,6 +340,8 @@ extern "C" int wb_model_destroy(WbModel *model) {
     if (model->stages_u8_dev) (void)hipFree(model->stages_u8_dev);
     if (model->stages_bin_dev) (void)hipFree(model->stages_bin_dev);
     if (model->bin_lut_dev) (void)hipFree(model->bin_lut_dev);
+    free(model->stages_u8_host);
+    free(model->stages_bin_host);
     void *g[] = {model->g_node_off, model->g_feat, model->g_thr, model->g_left, model->g_right, model->g_pred, model->g_theta};
     for (void *p : g)
         if (p) (void)hipFree(p);
@@ -348,5 +360,33 @@ extern "C" int wb_model_info(const WbModel *model, WbModelInfo *info) {
     info->tile_cols = WB_CASC_TC;
     info->lds_bytes = model->lds_bytes;
     info->rank_ok = model->bin_ok;
+    info->specialized = (model->jit_u8 ? 1 : 0) | (model->jit_bin ? 2 : 0);
     return WB_OK;
+}
+
+// The model-specialised kernel for one kind of byte tile (wb_jit.hip): compiled with hiprtc on first use (a couple of
+// seconds), then taken from the process / disk cache.  wb_cascade_launch uses it from then on for that channel dtype.
+extern "C" int wb_model_specialize(WbModel *model, int chn_dtype) {
+    WB_REQUIRE(model, "wb_model_specialize: null model");
+    if (chn_dtype != WB_DTYPE_U8 && chn_dtype != WB_DTYPE_RANK8) {
+        wb_set_error("wb_model_specialize: channel dtype %d has no specialised kernel (uint8 channels and threshold ranks do)", chn_dtype);
+        return WB_ERR_UNSUPPORTED;
+    }
+    if (model->generic || model->n_stages == 0) {
+        wb_set_error("wb_model_specialize: this model runs on the generic node-walk kernel (depth %d, %d stages)", model->depth, model->n_stages);
+        return WB_ERR_UNSUPPORTED;
+    }
+    const bool ranks = chn_dtype == WB_DTYPE_RANK8;
+    if (ranks && !model->bin_ok) {
+        wb_set_error("wb_model_specialize: this model has no rank tables (wb_model_info: rank_ok)");
+        return WB_ERR_UNSUPPORTED;
+    }
+    void **slot = ranks ? &model->jit_bin : &model->jit_u8;
+    if (*slot) return WB_OK;
+    if (!model->lds_stages) {
+        wb_set_error("wb_model_specialize: %d stages exceed the LDS mirror of the stage table the specialised kernel reads leaf values from", model->n_stages);
+        return WB_ERR_UNSUPPORTED;
+    }
+    return wb_jit_get(ranks ? model->stages_bin_host : model->stages_u8_host, model->stage_words, model->n_stages,
+                      model->depth, model->rpw, model->waves, model->C, model->lds_rows, model->lds_pitch, slot);
 }

@@ -86,6 +86,10 @@ struct WbModel {
     int bin_lut_vec;            // size of the table block in 16-byte units
     uint8_t *bin_lut_dev;       // float S[4][256] (sorted thresholds, +inf padded), then uint8 base[4][N]
     int32_t *stages_bin_dev;    // stage records for the binned tile: byte-tile offsets, thresholds = ranks
+    // model-specialised kernels (wb_jit.hip, wb_model_specialize): hipFunction_t per byte-tile stage table, or null
+    int32_t *stages_u8_host, *stages_bin_host;   // host copies of the two byte-tile tables the generator bakes in
+    size_t stage_words;                          // (n_stages + G) * stage_dwords
+    void *jit_u8, *jit_bin;
     // trees deeper than WB_CASC_MAX_DEPTH: generic node-walk kernel on the reference's own flat arrays
     int generic;                // 1 = use cascade_generic_kernel
     int32_t *g_node_off;        // [n_stages + 1]

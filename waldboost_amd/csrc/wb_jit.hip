@@ -1,0 +1,240 @@
+// Model-specialised cascade kernels: hiprtc compiles wb_cascade_tile.h -- the SAME source the generic kernels are
+// built from -- behind a generated prelude that makes the stage records of ONE model compile-time constants
+// (wb_model_specialize).  Feature offsets become LDS instruction offsets, thresholds, leaf values and theta become
+// literals, the scalar record loads and the moves in front of the selects disappear from phase A and from the
+// wave-synchronous segments.  The generic kernels stay the cold path (and the only path for float32 tiles).
+//
+// Replaces nothing new of the reference: it is wb_cascade_launch's kernel (model.py:216-259, training.py:84-96)
+// for a model that is scanned often enough to be worth ~2 s of compilation.  Compiled code objects are kept in
+// the process and in a cache directory ($WB_JIT_CACHE, default ~/.cache/waldboost_amd), keyed by a hash of the
+// generated source, the target and the hiprtc version.
+#include <hip/hiprtc.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "wb_common.h"
+
+int wb_cascade_group(int depth);   // wb_cascade.hip
+
+namespace {
+
+const char kTileSrc[] =
+#include "wb_cascade_tile.inc"
+    ;
+
+struct JitKernel {
+    hipModule_t module = nullptr;
+    hipFunction_t func = nullptr;
+};
+
+std::mutex g_mu;
+std::map<uint64_t, JitKernel> g_loaded;      // per process: hash -> loaded module (never unloaded)
+
+uint64_t fnv1a(const void *p, size_t n, uint64_t h = 1469598103934665603ull) {
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < n; ++i) {
+        h ^= b[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+// the stage segments run_segments walks for a cascade of T stages (wb_cascade_tile.h: t_end = min(2 t, T, t + 64),
+// from stage 8 on; the re-count at stage 16 splits nothing: 16 is on the chain)
+std::string segment_list(int T) {
+    std::string s;
+    for (int t = 8; t < T;) {
+        int e = 2 * t < T ? 2 * t : T;
+        e = e < t + 64 ? e : t + 64;
+        s += " X(" + std::to_string(t) + "," + std::to_string(e) + ")";
+        t = e;
+    }
+    return s;
+}
+
+std::string make_source(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch) {
+    std::string s;
+    s.reserve(n_words * 12 + 1024);
+    s += "#define WB_JIT_BAKED 1\n#define WB_JIT_STAGE_WORDS ";
+    for (size_t i = 0; i < n_words; ++i) {
+        if (i) s += ',';
+        s += std::to_string(words[i]);
+    }
+    s += "\n#define WB_JIT_SEGMENTS(X)" + segment_list(T) + "\n";
+    s += "#define WB_JIT_T " + std::to_string(T) + "\n#define WB_JIT_C " + std::to_string(C) + "\n#define WB_JIT_ROWS " +
+         std::to_string(rows) + "\n#define WB_JIT_PITCH " + std::to_string(pitch) + "\n";
+    s += "#include \"wb_cascade_tile.h\"\n";
+    // (8 waves per SIMD, as the generic kernel reaches on its own with 41 registers: the byte tile admits 4 workgroups per CU)
+    s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(waves * 64) +
+         ") __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void wb_casc_jit(CascArgs a, const int32_t *stages) {\n"
+         "    cascade_tile_body<" + std::to_string(D) + ", " + std::to_string(rpw) + ", " + std::to_string(waves) +
+         ", true, true>(a, stages);\n}\n";
+    return s;
+}
+
+std::string cache_dir() {
+    if (const char *e = getenv("WB_JIT_CACHE")) return *e ? std::string(e) : std::string();
+    if (const char *h = getenv("HOME")) return std::string(h) + "/.cache/waldboost_amd";
+    return std::string();
+}
+
+bool read_file(const std::string &path, std::vector<char> &out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize(n > 0 ? (size_t)n : 0);
+    const bool ok = n > 0 && fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+    fclose(f);
+    return ok;
+}
+
+void write_file_atomic(const std::string &dir, const std::string &path, const std::vector<char> &data) {
+    if (dir.empty()) return;
+    const size_t slash = dir.rfind('/');
+    if (slash != std::string::npos && slash > 0) (void)mkdir(dir.substr(0, slash).c_str(), 0755);
+    (void)mkdir(dir.c_str(), 0755);
+    const std::string tmp = path + "." + std::to_string((long)getpid()) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
+}
+
+// source -> code object for `arch` (no HIP runtime call: works without a GPU)
+int compile(const std::string &src, const char *arch, std::vector<char> &code, std::string &log) {
+    hiprtcProgram prog;
+    const char *hdr_src[] = {kTileSrc};
+    const char *hdr_name[] = {"wb_cascade_tile.h"};
+    hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "wb_casc_jit.hip", 1, hdr_src, hdr_name);
+    if (r != HIPRTC_SUCCESS) {
+        log = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r);
+        return WB_ERR_HIP;
+    }
+    const std::string a = std::string("--offload-arch=") + arch;
+    const char *opts[] = {a.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pragma-once-outside-header", "-Wno-inline-asm"};
+    r = hiprtcCompileProgram(prog, 6, opts);
+    size_t ls = 0;
+    if (hiprtcGetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
+        log.resize(ls);
+        (void)hiprtcGetProgramLog(prog, &log[0]);
+    }
+    if (getenv("WB_JIT_VERBOSE") && !log.empty()) fprintf(stderr, "[wb_jit] %s\n", log.c_str());
+    if (r != HIPRTC_SUCCESS) {
+        const size_t at = log.find("error:");                     // (warnings first: show the first error)
+        if (at != std::string::npos) log = log.substr(at > 120 ? at - 120 : 0);
+        log = std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(r) + "\n" + log;
+        (void)hiprtcDestroyProgram(&prog);
+        return WB_ERR_HIP;
+    }
+    size_t cs = 0;
+    r = hiprtcGetCodeSize(prog, &cs);
+    if (r == HIPRTC_SUCCESS) {
+        code.resize(cs);
+        r = hiprtcGetCode(prog, code.data());
+    }
+    (void)hiprtcDestroyProgram(&prog);
+    if (const char *d = getenv("WB_JIT_DUMP_DIR")) {            // diagnostic: the generated source and the code object
+        const std::string base = std::string(d) + "/wb_casc_jit";
+        if (FILE *f = fopen((base + ".hip").c_str(), "w")) { fwrite(src.data(), 1, src.size(), f); fclose(f); }
+        if (FILE *f = fopen((base + ".co").c_str(), "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
+    }
+    if (r != HIPRTC_SUCCESS || code.empty()) {
+        log = std::string("hiprtcGetCode: ") + hiprtcGetErrorString(r);
+        return WB_ERR_HIP;
+    }
+    return WB_OK;
+}
+
+}  // namespace
+
+// Build (or fetch) the specialised kernel for one stage table of `M`.  words: (T + G) records of SD dwords as uploaded.
+int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch, void **func_out) {
+    *func_out = nullptr;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    WB_HIP_CHECK(hipGetDevice(&dev));
+    WB_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    const std::string src = make_source(words, n_words, T, D, rpw, waves, C, rows, pitch);
+    int rtc_major = 0, rtc_minor = 0;
+    (void)hiprtcVersion(&rtc_major, &rtc_minor);
+    uint64_t h = fnv1a(src.data(), src.size());
+    h = fnv1a(kTileSrc, sizeof(kTileSrc), h);
+    h = fnv1a(prop.gcnArchName, strlen(prop.gcnArchName), h);
+    h = fnv1a(&rtc_major, sizeof(int), fnv1a(&rtc_minor, sizeof(int), h));
+    h = fnv1a(&dev, sizeof(int), h);                         // (a module is loaded per device)
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_loaded.find(h);
+    if (it != g_loaded.end()) {
+        *func_out = it->second.func;
+        return WB_OK;
+    }
+    char name[40];
+    snprintf(name, sizeof(name), "%016llx.co", (unsigned long long)h);
+    const std::string dir = cache_dir(), path = dir.empty() ? std::string() : dir + "/" + name;
+    std::vector<char> code;
+    if (path.empty() || !read_file(path, code)) {
+        std::string log;
+        const int rc = compile(src, prop.gcnArchName, code, log);
+        if (rc != WB_OK) {
+            wb_set_error("wb_model_specialize: %.400s", log.c_str());
+            return rc;
+        }
+        if (!path.empty()) write_file_atomic(dir, path, code);
+    }
+    JitKernel k;
+    hipError_t e = hipModuleLoadData(&k.module, code.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&k.func, k.module, "wb_casc_jit");
+    if (e != hipSuccess) {
+        if (!path.empty()) (void)unlink(path.c_str());          // (a stale or damaged cache entry: compile again next time)
+        wb_set_error("wb_model_specialize: loading the compiled kernel failed: %s", hipGetErrorString(e));
+        return WB_ERR_HIP;
+    }
+    g_loaded[h] = k;
+    *func_out = k.func;
+    return WB_OK;
+}
+
+// Compile check without a GPU (the CPU test suite): a synthetic cascade of n_stages random depth-`depth` trees through
+// the same generator and hiprtc for `arch`.  Returns the code object's size in *code_bytes.
+extern "C" int wb_jit_compile_check(int depth, int n_stages, const char *arch, int64_t *code_bytes) {
+    WB_REQUIRE(depth >= 1 && depth <= WB_CASC_MAX_DEPTH && n_stages >= 1 && n_stages <= 4096 && arch && code_bytes,
+               "wb_jit_compile_check: bad argument");
+    const int SD = WB_STAGE_DWORDS(depth), NI = WB_STAGE_NI(depth), NL = WB_STAGE_NL(depth), G = wb_cascade_group(depth);
+    std::vector<int32_t> words((size_t)(n_stages + G) * SD, 0);
+    uint32_t x = 12345u;
+    auto rnd = [&]() { return x = x * 1664525u + 1013904223u; };
+    for (int s = 0; s < n_stages + G; ++s) {
+        int32_t *rec = words.data() + (size_t)s * SD;
+        float *f = reinterpret_cast<float *>(rec);
+        if (s >= n_stages) {
+            f[2 * NI + NL] = -INFINITY;
+            continue;
+        }
+        for (int i = 0; i < NI; ++i) {
+            rec[i] = (int32_t)(rnd() % 3000u);
+            rec[NI + i] = (int32_t)(rnd() % 255u);
+        }
+        for (int i = 0; i < NL; ++i) f[2 * NI + i] = (float)(rnd() % 2000u) * 1e-3f - 1.0f;
+        f[2 * NI + NL] = s % 7 == 3 ? -INFINITY : -0.5f * (float)s;
+    }
+    const std::string src = make_source(words.data(), words.size(), n_stages, depth, 4, 8, 4, 4 * 8 + 11, WB_CASC_TC + 12);
+    std::vector<char> code;
+    std::string log;
+    const int rc = compile(src, arch, code, log);
+    if (rc != WB_OK) {
+        wb_set_error("wb_jit_compile_check: %.400s", log.c_str());
+        return rc;
+    }
+    *code_bytes = (int64_t)code.size();
+    return WB_OK;
+}

@@ -20,6 +20,11 @@ from .plan import PyramidPlan, N_CHANNELS
 _TORCH_DT = {}
 _NO_DETECT_GRAPH = bool(int(os.environ.get("WB_NO_DETECT_GRAPH", "0")))
 _NO_RANKS = bool(os.environ.get("WB_NO_RANKS"))     # diagnostic: float32 channels + planar float tile everywhere
+# Model-specialised cascade kernels (csrc/wb_jit.hip): a cascade that has been scanned this many times on byte tiles is
+# compiled with its stage records as constants (hiprtc, ~2 s once; cached on disk).  WB_CASC_JIT=0: never automatically
+# (DeviceCascade.specialize() still works), WB_CASC_JIT_AFTER=n: after n scans (default 3).
+_JIT_AUTO = os.environ.get("WB_CASC_JIT", "1") != "0"
+_JIT_AFTER = int(os.environ.get("WB_CASC_JIT_AFTER", "3"))
 
 
 def _torch_dtype(np_dtype):
@@ -123,6 +128,47 @@ class DeviceCascade:
         # the model's thresholds fit rank tables: the channel kernel can write float32 channels as one-byte ranks
         # (WB_DTYPE_RANK8) and the cascade scan them exactly as it would the floats, from a quarter of the bytes
         self.rank_ok = bool(info.rank_ok)
+        self._scans = {}                 # byte-tile scans so far, per channel dtype code
+        self._jit_failed = set()
+
+    def specialized(self):
+        """Which byte tiles have a model-specialised kernel loaded: subset of {WB_DTYPE_U8, WB_DTYPE_RANK8}."""
+        info = nat.WbModelInfo()
+        nat.check(self._lib.wb_model_info(self.handle, C.byref(info)), "wb_model_info")
+        return {d for bit, d in ((1, nat.WB_DTYPE_U8), (2, nat.WB_DTYPE_RANK8)) if info.specialized & bit}
+
+    def specialize(self, chn_dtype=None):
+        """Compile and load the model-specialised tile kernel (wb_model_specialize) for a kind of byte tile: the threshold
+        ranks by default when the model has rank tables, else uint8 channels.  Returns False when this model has no
+        specialised kernel (node-walk models, cascades beyond the LDS mirror); raises NativeError if the compiler fails."""
+        if chn_dtype is None:
+            chn_dtype = nat.WB_DTYPE_RANK8 if self.rank_ok else nat.WB_DTYPE_U8
+        rc = self._lib.wb_model_specialize(self.handle, chn_dtype)
+        if rc == nat.WB_ERR_UNSUPPORTED:
+            return False
+        nat.check(rc, "wb_model_specialize")
+        return True
+
+    def note_scan(self, chn_dtype, force=False):
+        """Called by the engine before a scan on byte tiles: after _JIT_AFTER scans (force: now -- Model.detect is about
+        to capture its graph) the cascade is worth specialising.  Never inside a stream capture (compilation and module
+        loading are not capturable), never twice after a failure."""
+        if not _JIT_AUTO or chn_dtype == nat.WB_DTYPE_F32 or chn_dtype in self._jit_failed:
+            return
+        n = self._scans.get(chn_dtype, 0) + 1
+        if force and n < _JIT_AFTER:
+            n = _JIT_AFTER
+        self._scans[chn_dtype] = n
+        if n == _JIT_AFTER:
+            import torch
+            if torch.cuda.is_current_stream_capturing():
+                self._scans[chn_dtype] = n - 1
+                return
+            try:
+                if not self.specialize(chn_dtype):
+                    self._jit_failed.add(chn_dtype)
+            except nat.NativeError:
+                self._jit_failed.add(chn_dtype)      # (stay on the generic kernel; the message is in wb_last_error)
 
     def __del__(self):
         try:
@@ -417,6 +463,7 @@ class PyramidEngine:
             return stt
         if ranks and self.rank_owner is not dm:
             raise RuntimeError("the rank buffer does not hold this cascade's ranks (launch_channels(rank_dm=...) first)")
+        dm.note_scan(nat.WB_DTYPE_RANK8 if ranks else self.spec.wb_dtype)
         nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.rank if ranks else self.chn),
                                              nat.WB_DTYPE_RANK8 if ranks else self.spec.wb_dtype,
                                              self.chn_stride,
@@ -619,6 +666,8 @@ class PyramidEngine:
         g = stt.get("graph")
         if g is None and stt.get("detect_calls", 0) >= 1 and not _NO_DETECT_GRAPH:
             # (the first call ran eagerly: every lazily allocated buffer exists, the kernels are loaded)
+            # a cascade that is scanned again is worth its specialised kernel -- built now, so that the graph holds it
+            dm.note_scan(nat.WB_DTYPE_RANK8 if self.ranks_for(dm) else self.spec.wb_dtype, force=True)
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             with torch.cuda.graph(g):
