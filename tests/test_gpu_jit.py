@@ -104,8 +104,12 @@ def test_auto_specialisation_after_a_few_scans_and_models_it_cannot_take():
         e.run(dm2)
         assert bool(dm2.specialized()) == (i + 1 >= engine._JIT_AFTER and engine._JIT_AUTO)
     # a cascade of trees deeper than the tile kernel walks runs on the node-walk kernel: nothing to specialise
-    deep = random_model(3, 6, lambda rng: 5)
-    assert deep.device_cascade().specialize() is False
+    from test_gpu_parity import _random_deep_tree
+    rng = np.random.default_rng(3)
+    deep = wb.Model((12, 12, 4), dict(wb.default_channel_opts))
+    for t in range(6):
+        deep.append(wb.DTree(*_random_deep_tree(rng, (12, 12, 4), 5)), float(np.float32(-0.4 * (t + 1))))
+    assert deep.device_cascade().depth >= 4 and deep.device_cascade().specialize() is False
     assert_same(deep.detect_raw(img), oracle_detect(deep, img))
     # float32 channel tiles have no specialised kernel
     assert dm.specialize(nat.WB_DTYPE_F32) is False

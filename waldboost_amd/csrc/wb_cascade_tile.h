@@ -64,6 +64,16 @@ __host__ __device__ constexpr size_t wb_lds_stab_off(bool u8, int C, int rows, i
     return (wb_lds_tile_bytes(u8, C, rows, pitch) + (size_t)TR * 64 * 8 + (size_t)T * 4 + 15) & ~(size_t)15;
 }
 #define WB_LDS_CTL_BYTES 128
+// experiment switches (A/B builds; the defaults are what measured best)
+#ifndef WB_TAIL_W
+#define WB_TAIL_W 2          // windows the stage-parallel tail walks side by side
+#endif
+#ifndef WB_TAIL_ALL
+#define WB_TAIL_ALL 1        // tail: gather every node's feature up front (eval_all)
+#endif
+#ifndef WB_SEG_PREFETCH
+#define WB_SEG_PREFETCH 1    // BAKED segments: next group's gathers before this group's rejection tests
+#endif
 
 template <bool BAKED> __device__ __forceinline__ const int32_t *wb_stage_table(const int32_t *stages) {
     if constexpr (BAKED)
@@ -161,6 +171,24 @@ template <int D> struct Stage {
         } else {
             const float v = *reinterpret_cast<const float *>(t8 + at);
             return !(v <= th);                         // NaN goes right, like the reference's `<=`
+        }
+    }
+    // the same walk with EVERY node's feature gathered up front (depth <= 2): one LDS round trip instead of one per level,
+    // no selects of offsets or thresholds -- for records that sit in vector registers (the stage-parallel tail: one stage
+    // per lane), where the selects of the leaf values cost no moves
+    template <bool BYTES = false> __device__ inline float eval_all(const float *tile, int base) const {
+        if constexpr (D > 2) {
+            return eval<BYTES>(tile, base);
+        } else {
+            const char *t8 = reinterpret_cast<const char *>(tile);
+            const bool r0 = goes_right<BYTES>(t8, base + off[0], thr[0]);
+            if constexpr (D == 1) {
+                return r0 ? pred[1] : pred[0];
+            } else {
+                const bool rl = goes_right<BYTES>(t8, base + off[1], thr[1]), rr = goes_right<BYTES>(t8, base + off[2], thr[2]);
+                const float pl = rl ? pred[1] : pred[0], pr = rr ? pred[3] : pred[2];
+                return r0 ? pr : pl;
+            }
         }
     }
     template <bool BYTES = false> __device__ inline float eval(const float *tile, int base) const {
@@ -587,13 +615,23 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
                         constexpr int TB = Seg::tb, TE = Seg::te;
                         // (compile-time recursion instead of `#pragma unroll`: the optimiser declines to unroll a long
                         // loop with an early exit, and every index below must be a constant)
+                        // (software-pipelined: the gathers of group t + G are issued before group t's sums and rejection
+                        // tests -- the early exit between groups otherwise puts a full LDS round trip in front of every group)
+                        float pc[G];
+                        wb_static_for<0, G, 1>([&](auto gg) {
+                            constexpr int g = decltype(gg)::value;
+                            pc[g] = StageAt<D, U8, TR, TB + g>::eval(tile, wbase);
+                            return true;
+                        });
                         wb_static_for<TB, TE, G>([&](auto tt) {
                             constexpr int t = decltype(tt)::value;
-                            if (am == 0ull) return false;
-                            float p[G];
+                            float pn[G];
                             wb_static_for<0, G, 1>([&](auto gg) {
                                 constexpr int g = decltype(gg)::value;
-                                p[g] = StageAt<D, U8, TR, t + g>::eval(tile, wbase);
+                                if constexpr (WB_SEG_PREFETCH && t + G < TE)
+                                    pn[g] = StageAt<D, U8, TR, t + G + g>::eval(tile, wbase);
+                                else
+                                    pn[g] = 0.0f;
                                 return true;
                             });
                             wb_static_for<0, G, 1>([&](auto gg) {
@@ -602,9 +640,18 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
                                     const int cnt = __popcll(am);
                                     asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(ent_c) : "s"(cnt), "n"(t + g - TB));
                                     const float theta = StageAt<D, U8, TR, t + g>::theta();
-                                    h = h + p[g];
+                                    h = h + pc[g];
                                     am &= __ballot(h >= theta) | (never_rejects<true>(theta) ? ~0ull : 0ull);
                                 }
+                                return true;
+                            });
+                            if (am == 0ull) return false;
+                            wb_static_for<0, G, 1>([&](auto gg) {
+                                constexpr int g = decltype(gg)::value;
+                                if constexpr (WB_SEG_PREFETCH)
+                                    pc[g] = pn[g];
+                                else if constexpr (t + G < TE)
+                                    pc[g] = StageAt<D, U8, TR, t + G + g>::eval(tile, wbase);
                                 return true;
                             });
                             return true;
@@ -720,46 +767,80 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
         }
         int n_out = 0;
         uint32_t entered_t = 0;                                  // windows that entered stage rs + lane in this pass
-        for (int i = 0; i < n_q; ++i) {
-            const uint2 e = queue[i * qs];                       // same entry in every lane
-            const int pos = __builtin_amdgcn_readfirstlane((int)e.x);
-            const int wbase = ((pos >> 6) * pitch + (pos & 63)) * px_stride;
-            const float p = st.template eval<U8>(tile, wbase);
-            // Replay in stage order: lane k accumulates p_0 .. p_k one after the other -- the same
-            // additions in the same order as the reference's running `hs +=` -- so it ends up
-            // with the score the rejection test of stage rs+k sees.
-            // (ripple through the wave with DPP wave_shr:1 -- lane k takes lane k-1's running sum
-            // and adds its own p; after step j lanes 0..j are final and later steps recompute the
-            // same value, so 63 steps settle every lane)
-            // Lane 0 folds the incoming score into its addend (0 + x == x exactly), so the shifted-in
-            // value of the out-of-range lane can be the DPP zero (bound_ctrl) and each step is ONE
-            // v_add_f32 with a wave_shr:1 source.
+        // W windows at a time (W = 2 while the queue holds a pair): a window's chain -- gathers, leaf select, the DPP
+        // ripple below -- is all latency, and two independent chains interleave in the same issue slots
+        auto windows = [&](auto w_tag, int i) {
+            constexpr int W = decltype(w_tag)::value;
+            int pos[W];
+            float pk[W], hk[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const uint2 e = queue[(i + w) * qs];                 // same entry in every lane
+                pos[w] = __builtin_amdgcn_readfirstlane((int)e.x);
+                const int wbase = ((pos[w] >> 6) * pitch + (pos[w] & 63)) * px_stride;
+                const float p = WB_TAIL_ALL ? st.template eval_all<U8>(tile, wbase) : st.template eval<U8>(tile, wbase);
+                // Replay in stage order: lane k accumulates p_0 .. p_k one after the other -- the same
+                // additions in the same order as the reference's running `hs +=` -- so it ends up
+                // with the score the rejection test of stage rs+k sees.
+                // (ripple through the wave with DPP wave_shr:1 -- lane k takes lane k-1's running sum
+                // and adds its own p; after step j lanes 0..j are final and later steps recompute the
+                // same value, so 63 steps settle every lane)
+                // Lane 0 folds the incoming score into its addend (0 + x == x exactly), so the shifted-in
+                // value of the out-of-range lane can be the DPP zero (bound_ctrl) and each step is ONE
+                // v_add_f32 with a wave_shr:1 source.
+                const float h_in = __uint_as_float(e.y);
+                pk[w] = lane == 0 ? h_in + p : p;
+                hk[w] = pk[w];
+            }
             // Most windows are rejected within a few stages, so the ripple runs in blocks of 8 steps and stops
             // at the first block whose settled lanes hold a rejection: the lowest such lane is the first
-            // rejecting stage (every earlier stage is settled and passed).
-            const float h_in = __uint_as_float(e.y);
-            const float pk = lane == 0 ? h_in + p : p;
-            float hk = pk;
-            unsigned long long rmask;
+            // rejecting stage (every earlier stage is settled and passed).  (A window that is done keeps rippling
+            // beside its partner: its settled lanes recompute the same sums, its verdict is frozen.)
+            unsigned long long rmask[W];
+            bool done[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                rmask[w] = 0ull;
+                done[w] = false;
+            }
             for (int settled = 1;;) {                            // lanes [0, settled) hold their final sums
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    int prev = __builtin_amdgcn_update_dpp(0, __float_as_int(hk), 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-                    hk = __int_as_float(prev) + pk;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        int prev = __builtin_amdgcn_update_dpp(0, __float_as_int(hk[w]), 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+                        hk[w] = __int_as_float(prev) + pk[w];
+                    }
                 }
                 settled += 8;
                 const int upto = settled < nvalid ? settled : nvalid;
-                rmask = __ballot((lane < upto) && (st.theta != -INFINITY) && !(hk >= st.theta));
-                if (rmask || settled >= nvalid) break;
+                bool all = true;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    if (!done[w]) {
+                        rmask[w] = __ballot((lane < upto) && (st.theta != -INFINITY) && !(hk[w] >= st.theta));
+                        done[w] = rmask[w] || settled >= nvalid;
+                    }
+                    all = all && done[w];
+                }
+                if (all) break;
             }
-            const int last = rmask ? (int)__builtin_ctzll(rmask) : nvalid - 1;   // last stage entered
-            entered_t += lane <= last ? 1u : 0u;
-            if (!rmask) {
-                float hl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hk), nvalid - 1));
-                if (lane == 0) queue[n_out * qs] = make_uint2((uint32_t)pos, __float_as_uint(hl));   // n_out <= i
-                ++n_out;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const int last = rmask[w] ? (int)__builtin_ctzll(rmask[w]) : nvalid - 1;   // last stage entered
+                entered_t += lane <= last ? 1u : 0u;
+                if (!rmask[w]) {
+                    float hl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hk[w]), nvalid - 1));
+                    if (lane == 0) queue[n_out * qs] = make_uint2((uint32_t)pos[w], __float_as_uint(hl));   // n_out <= i + w: entries read above
+                    ++n_out;
+                }
             }
-        }
+        };
+        int i = 0;
+        if constexpr (WB_TAIL_W == 2)
+            for (; i + 1 < n_q; i += 2) windows(WbInt<2>{}, i);
+        for (; WB_TAIL_W != 2 && i + 1 < n_q; ++i) windows(WbInt<1>{}, i);
+        if (i < n_q) windows(WbInt<1>{}, i);
         if (entered_t) atomicAdd(&hist[t], entered_t);           // (lanes >= nvalid never count: last < nvalid)
         n_q = n_out;
     }

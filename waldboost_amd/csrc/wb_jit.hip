@@ -121,8 +121,22 @@ int compile(const std::string &src, const char *arch, std::vector<char> &code, s
         return WB_ERR_HIP;
     }
     const std::string a = std::string("--offload-arch=") + arch;
-    const char *opts[] = {a.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pragma-once-outside-header", "-Wno-inline-asm"};
-    r = hiprtcCompileProgram(prog, 6, opts);
+    std::vector<std::string> extra;                          // diagnostic: WB_JIT_DEFS="-DWB_TAIL_W=1 -D..." (A/B builds)
+    if (const char *e = getenv("WB_JIT_DEFS")) {
+        std::string cur;
+        for (const char *c = e;; ++c) {
+            if (*c == ' ' || *c == 0) {
+                if (!cur.empty()) extra.push_back(cur);
+                cur.clear();
+                if (!*c) break;
+            } else {
+                cur += *c;
+            }
+        }
+    }
+    std::vector<const char *> opts = {a.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pragma-once-outside-header", "-Wno-inline-asm"};
+    for (const std::string &x : extra) opts.push_back(x.c_str());
+    r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     size_t ls = 0;
     if (hiprtcGetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
         log.resize(ls);
@@ -172,6 +186,7 @@ int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int 
     h = fnv1a(prop.gcnArchName, strlen(prop.gcnArchName), h);
     h = fnv1a(&rtc_major, sizeof(int), fnv1a(&rtc_minor, sizeof(int), h));
     h = fnv1a(&dev, sizeof(int), h);                         // (a module is loaded per device)
+    if (const char *e = getenv("WB_JIT_DEFS")) h = fnv1a(e, strlen(e), h);
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_loaded.find(h);
     if (it != g_loaded.end()) {
