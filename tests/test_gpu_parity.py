@@ -630,3 +630,39 @@ def test_window_too_large_for_an_lds_tile_falls_back_to_the_generic_kernel():
     ors, ocs, ohs, oalive = orc.cascade_predict_on_image(sh, trees, thetas, X)
     assert ors.size > 0
     assert np.array_equal(rs, ors) and np.array_equal(cs, ocs) and np.array_equal(bits(hs), bits(ohs)) and np.array_equal(alive, oalive)
+
+
+# ------------------------------------------------------------------------------ non-finite pixels
+@pytest.mark.parametrize("kind", ["inf", "nan", "huge"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_channel_pyramid_and_detection_with_non_finite_pixels_vs_oracle(dtype, kind):
+    """Float images holding inf / NaN / nearly overflowing pixels (reference channels.py:132: scipy's zoom multiplies
+    every tap, so an identity level is NOT a copy next to an infinite pixel -- 0 * inf = NaN -- and NumPy's clip hands a
+    NaN min / max on to the whole level; :61-64 pools them into the octaves; :52 np.fmax turns NaN gradients into 0).
+    Every level of the pyramid against the oracle, bit for bit where it is not NaN, NaN where it is; then a detection."""
+    from test_oracle import nonfinite_image
+    from waldboost_amd.channels import channel_pyramid
+    import scipy.ndimage as ndi
+    img = nonfinite_image((136, 200), dtype, kind)
+    opts = dict(wb.default_channel_opts)
+    with np.errstate(invalid="ignore", over="ignore"):
+        # (the oracle's own resize on this very image against SciPy, on this machine: level 1 of octave 0)
+        nh, nw = 124, 182
+        z = np.clip(ndi.zoom(img, [nh / 136, nw / 200], order=1, mode="mirror", grid_mode=True), img.min(), img.max())
+        o = orc.resize_bilinear(img, nh, nw)
+        assert np.array_equal(np.isnan(o), np.isnan(z)) and np.array_equal(o[~np.isnan(z)], z[~np.isnan(z)])
+        ref = list(orc.channel_pyramid(img, dict(opts, channels=orc.grad_hist)))
+    got = list(channel_pyramid(img, opts))
+    assert len(got) == len(ref) > 8
+    n_special = 0
+    for (c, s), (rc, rs) in zip(got, ref):
+        assert s == rs and c.shape == rc.shape
+        nan = np.isnan(rc)
+        assert np.array_equal(np.isnan(c), nan)
+        assert np.array_equal(bits(c)[~nan], bits(rc)[~nan])
+        n_special += int(np.isinf(rc).sum()) + int(nan.sum())
+    assert kind != "inf" or n_special > 0
+    M = random_model(21, 20, 2)
+    with np.errstate(invalid="ignore", over="ignore"):
+        want = oracle_detect(M, img)
+    assert_same_detections(M.detect_raw(img), want)

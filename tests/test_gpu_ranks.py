@@ -107,8 +107,9 @@ def test_special_thresholds_and_float_images_that_overflow():
     imf[90, 20] = -3.0e38
     with np.errstate(invalid="ignore", over="ignore"):
         assert check_ranks(M, imf) > 0                       # there are infinite pixels
-    # (no oracle comparison on this image: pixel values next to FLT_MAX are outside what the float32 resample path
-    # is pinned for -- 0 * inf in the bilinear taps; the ranks above are checked against the kernel's own floats)
+    # (pixel values next to FLT_MAX overflow in the octaves and in the gradients: inf and, through the zero-weight
+    # taps of scipy's zoom and convolve1d, NaN -- the kernels follow the oracle there too)
+    check_detect(M, imf)
     a = M.detect_raw(imf)
     shrink, n_per_oct, smooth, spec = read_opts(M.channel_opts)
     eng = _engine.get_engine(imf.shape[0], imf.shape[1], imf.dtype, shrink, n_per_oct, smooth, 1, channels=spec)

@@ -181,6 +181,44 @@ def test_resize_equals_scipy_zoom(shape, out, dtype):
     assert got.dtype == dtype and np.array_equal(got, want)
 
 
+def nonfinite_image(shape, dtype, kind, seed=5):
+    """A float image with a few non-finite (or nearly overflowing) pixels: what reference channels.py:132 does with
+    them is scipy's zoom -- every tap is multiplied, 0 * inf = NaN -- and NumPy's clip."""
+    img = (synth_image(shape[0], shape[1], seed).astype(dtype) * dtype(0.25)).astype(dtype)
+    big = np.finfo(np.float32).max
+    if kind == "inf":
+        img[7, 11] = np.inf
+        img[shape[0] - 1, 3] = -np.inf                   # on the border: the mirrored tap
+        img[20:22, 30:33] = np.inf
+    elif kind == "nan":
+        img[9, 14] = np.nan
+    elif kind == "huge":
+        img[5:9, 8:12] = big
+        img[17, 40] = -big
+        img[30, 2] = big * dtype(0.75)
+    return img
+
+
+@pytest.mark.parametrize("kind", ["inf", "nan", "huge"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,out", [((64, 96), (64, 96)), ((97, 131), (80, 110)), ((66, 90), (36, 50))])
+def test_resize_of_non_finite_pixels_equals_scipy_zoom(shape, out, dtype, kind):
+    """Pins S3 off the beaten track: identity levels are NOT a copy next to an infinite pixel (its zero-weight taps
+    give NaN), a NaN pixel makes min / max and with them the whole clipped level NaN."""
+    img = nonfinite_image(shape, dtype, kind)
+    with np.errstate(invalid="ignore", over="ignore"):
+        z = ndi.zoom(img, [o / i for o, i in zip(out, shape)], order=1, mode="mirror", grid_mode=True)
+        want = np.clip(z, img.min(), img.max())
+        got = orc.resize_bilinear(img, out[0], out[1])
+    assert got.dtype == dtype and np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.array_equal(got[ok], want[ok])
+    if kind == "inf":
+        assert np.isinf(want).any() and (np.isnan(want).any() or shape != out)      # identity: the zero-weight taps
+    if kind == "nan":
+        assert np.isnan(want).all()
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.float32])
 def test_gradients_equal_scipy_convolve1d(dtype):
     img = synth_image(75, 101, 3, dtype).astype("f")

@@ -124,25 +124,35 @@ template <> struct Src<uint8_t> {
         t = fmin(fmax(t, mn), mx);
         return (float)(int)t;
     }
+    static __device__ bool taps_finite(uint8_t, uint8_t, uint8_t) { return true; }
     // [1,2,1] pass: exact in fp32 for integer pixels (|.| <= 1020); 2b is exact, so the fma rounds like b*2 + (a+c)
     static __device__ float hpass(float a, float b, float c) { return __builtin_fmaf(b, 2.0f, a + c); }
-    static __device__ float dpass(float lo, float hi) { return lo - hi; }
+    // [-1,0,1] pass: scipy multiplies the centre tap too (weight 0); integer pixels are finite, so it adds nothing
+    static __device__ float dpass(float lo, float, float hi) { return lo - hi; }
 };
 template <> struct Src<float> {
     static constexpr bool kFastResample = false;
     static __device__ bool fast(float, float, float, float, float, float, float, float, float &) { return false; }
     static __device__ bool fast_rows(float, float, float, float, float &) { return false; }
     static __device__ double lo(uint32_t k) { return (double)wb_key_f32(k); }
-    // float32 images: zoom stores fp32, then np.clip in fp32
+    // float32 images: zoom stores fp32, then np.clip in fp32 -- np.minimum(np.maximum(x, lo), hi), which hands a NaN
+    // through from x AND from a bound: an octave that holds a NaN pixel has a NaN min or max (wb_octaves.hip: the
+    // keys order NaNs outside +-inf) and every pixel resized from it is NaN, as under NumPy
     static __device__ float finish(double t, double mn, double mx, int) {
-        float f = (float)t;
-        return fminf(fmaxf(f, (float)mn), (float)mx);
+        const float f = (float)t, lo = (float)mn, hi = (float)mx;
+        if (lo != lo || hi != hi) return __builtin_nanf("");
+        return f < lo ? lo : (f > hi ? hi : f);              // (a NaN f fails both tests and stays)
     }
+    // a pixel copy stands for scipy's (v00*1)*1 + (v01*1)*0 + (v10*0)*1 + (v11*0)*0 only while the three taps of
+    // weight 0 are finite (0 * inf = NaN)
+    static __device__ bool taps_finite(float a, float b, float c) { return fabsf(a) < INFINITY && fabsf(b) < INFINITY && fabsf(c) < INFINITY; }
     // scipy correlate1d: fp64 accumulate, one fp32 rounding per pass
     static __device__ float hpass(float a, float b, float c) {
         return (float)((double)b * 2.0 + ((double)a + (double)c));
     }
-    static __device__ float dpass(float lo, float hi) { return (float)((double)lo - (double)hi); }
+    // the centre tap of weight 0 is part of the sum (correlate1d's antisymmetric branch): 0 * inf = NaN next to an
+    // infinite value, as under scipy; for a finite centre it adds +-0
+    static __device__ float dpass(float lo, float mid, float hi) { return (float)((double)mid * 0.0 + ((double)lo - (double)hi)); }
 };
 
 // float64 images, and integer images held as float64 (WB_DTYPE_F64 / WB_DTYPE_I8..U32): zoom in fp64, np.clip in
@@ -157,11 +167,13 @@ template <> struct Src<double> {
         return __longlong_as_double((long long)b);
     }
     static __device__ float finish(double t, double mn, double mx, int src_int) {
-        t = fmin(fmax(t, mn), mx);
+        if (mn != mn || mx != mx) return __builtin_nanf("");     // (np.clip with a NaN bound: see Src<float>::finish)
+        t = t < mn ? mn : (t > mx ? mx : t);
         return (float)(src_int ? trunc(t) : t);
     }
+    static __device__ bool taps_finite(double a, double b, double c) { return fabs(a) < INFINITY && fabs(b) < INFINITY && fabs(c) < INFINITY; }
     static __device__ float hpass(float a, float b, float c) { return Src<float>::hpass(a, b, c); }
-    static __device__ float dpass(float lo, float hi) { return Src<float>::dpass(lo, hi); }
+    static __device__ float dpass(float lo, float mid, float hi) { return Src<float>::dpass(lo, mid, hi); }
 };
 
 // the (min, max) an octave's resize result is clipped to, from the order-preserving keys the octave kernel left
@@ -592,8 +604,10 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
 #pragma unroll
                 for (int c = 0; c < NCS; ++c) {
                     float out = 0.0f;
-                    if (ident) {
-                        out = (float)v00[rb][c];
+                    if (ident && Src<T>::taps_finite(v01[rb][c], v10[rb][c], v11[rb][c])) {
+                        // (float32 / integer results pass the clip unchanged: the pixel lies in its octave's range;
+                        // a NaN bound turns every pixel of the level into NaN, also the copied ones)
+                        out = (mn != mn || mx != mx) ? __builtin_nanf("") : (float)v00[rb][c];
                     } else {
                         bool ok = false;
                         if constexpr (Src<T>::kFastResample)
@@ -637,8 +651,8 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             const T *r0 = src + (int64_t)tr.i0 * L.src_w;
             const T *r1 = src + (int64_t)tr.i1 * L.src_w;
             const T a00 = r0[tc.i0], a01 = r0[tc.i1], a10 = r1[tc.i0], a11 = r1[tc.i1];
-            ok = ident;
-            if (ident) out = (float)a00;
+            ok = ident && Src<T>::taps_finite(a01, a10, a11);
+            if (ok) out = (mn != mn || mx != mx) ? __builtin_nanf("") : (float)a00;
             if constexpr (Src<T>::kFastResample)
                 if (!ok) ok = Src<T>::fast((float)a00, (float)a01, (float)a10, (float)a11, (float)tr.w0, (float)tr.w1,
                                            (float)tc.w0, (float)tc.w1, out);
@@ -710,8 +724,8 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 || S == 4 ? 1 : 4) void channels
         for (int y = 0; y < S; ++y)
 #pragma unroll
             for (int x = 0; x < S; ++x) {
-                const float gx = scalar_only(Src<T>::dpass(hc[y][x], hc[y][x + 2]));
-                const float gy = scalar_only(Src<T>::dpass(hr[y][x], hr[y + 2][x]));
+                const float gx = scalar_only(Src<T>::dpass(hc[y][x], hc[y][x + 1], hc[y][x + 2]));
+                const float gy = scalar_only(Src<T>::dpass(hr[y][x], hr[y + 1][x], hr[y + 2][x]));
                 gxs[y][x] = gx;
                 gys[y][x] = gy;
                 if constexpr (TWO_PASS)
@@ -1155,8 +1169,8 @@ __global__ __launch_bounds__(256) void channels_gm_kernel(ChanArgs a) {
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             float out = 0.0f;
-            bool ok = ident;
-            if (ident) out = (float)a00[k];
+            bool ok = ident && Src<T>::taps_finite(a01[k], a10[k], a11[k]);
+            if (ok) out = (mn != mn || mx != mx) ? __builtin_nanf("") : (float)a00[k];
             if constexpr (Src<T>::kFastResample)
                 if (!ok) ok = Src<T>::fast((float)a00[k], (float)a01[k], (float)a10[k], (float)a11[k], (float)tr[k].w0,
                                            (float)tr[k].w1, (float)tc[k].w0, (float)tc[k].w1, out);
@@ -1174,7 +1188,9 @@ __global__ __launch_bounds__(256) void channels_gm_kernel(ChanArgs a) {
         const float hc2 = Src<T>::hpass(c[2], c[RW + 2], c[2 * RW + 2]);      //                     column q+2
         const float hr0 = Src<T>::hpass(c[0], c[1], c[2]);                    // horizontal [1,2,1] at row k
         const float hr2 = Src<T>::hpass(c[2 * RW], c[2 * RW + 1], c[2 * RW + 2]);
-        const float gx = Src<T>::dpass(hc0, hc2), gy = Src<T>::dpass(hr0, hr2);
+        const float hc1 = Src<T>::hpass(c[1], c[RW + 1], c[2 * RW + 1]);      // the centre taps (weight 0: see dpass)
+        const float hr1 = Src<T>::hpass(c[RW], c[RW + 1], c[RW + 2]);
+        const float gx = Src<T>::dpass(hc0, hc1, hc2), gy = Src<T>::dpass(hr0, hr1, hr2);
         Mg[p] = sqrtf(gx * gx + gy * gy);
     }
     __syncthreads();
