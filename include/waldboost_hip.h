@@ -241,6 +241,18 @@ int wb_model_info(const WbModel *model, WbModelInfo *info);
  * for models on the node-walk kernel; a failed compilation leaves the model on the generic kernel. */
 int wb_model_specialize(WbModel *model, int chn_dtype);
 
+/* Several cascades over ONE pyramid of threshold ranks (waldboost.detect(image, *models), reference __init__.py:120-124:
+ * the channels are computed once for all models): one rank table per channel from the UNION of the members'
+ * thresholds.  wb_rankgroup_model hands out member i as a VIEW of its model -- a WbModel handle owned by the group that
+ * shares everything with the model but the rank tables; pass any view as wb_channels_launch's rank_model (they hold
+ * the same table) and view i to wb_cascade_launch(WB_DTYPE_RANK8) / wb_model_specialize / wb_model_info.  The models
+ * must outlive the group.  WB_ERR_UNSUPPORTED when a channel's union exceeds 255 thresholds or a member has no rank
+ * form (node-walk models, C != 4): scan float32 channels then. */
+typedef struct WbRankGroup WbRankGroup;
+int wb_rankgroup_create(const WbModel *const *models, int n, WbRankGroup **out);
+int wb_rankgroup_model(WbRankGroup *group, int i, WbModel **view);
+int wb_rankgroup_destroy(WbRankGroup *group);
+
 /* Build check of the specialised kernel's source without a GPU: a synthetic cascade of n_stages depth-`depth` trees
  * through the generator and hiprtc for `arch` (e.g. "gfx950"); *code_bytes = size of the code object. */
 int wb_jit_compile_check(int depth, int n_stages, const char *arch, int64_t *code_bytes);

@@ -64,3 +64,27 @@ for N in (10_000, 1_000_000):
     H = torch.empty(N, dtype=torch.float32, device="cuda"); mask = torch.empty(N, dtype=torch.uint8, device="cuda")
     ms = t(lambda: nat.check(lib.wb_samples_predict_launch(nat.stream_ptr(), dm.handle, nat.ptr(out), nat.WB_DTYPE_F32, N, nat.ptr(H), nat.ptr(mask))), 10)
     print(f"Model.predict  N={N:8d}: {ms:8.3f} ms  {N / ms / 1e3:8.1f} M samples/s  ({N * 2304 / ms / 1e6:.1f} GB/s if every sample byte were read)")
+
+# waldboost.detect(image, M1, M2) (reference __init__.py:75-130): two 128-stage cascades over ONE pyramid, host ndarray in,
+# Boxes out.  Rank path: one byte pyramid of the union of both models' thresholds; float path: the float32 pyramid.
+import time
+from waldboost_amd import engine as E
+M1 = wb.load(os.path.join(ROOT, "tests/golden/models/cfg2_d2_T128.pb"))
+M2 = wb.load(os.path.join(ROOT, "tests/golden/models/cfg2_d2_T128.pb"))
+rng2 = np.random.default_rng(5)
+for w, _ in M2:
+    w.threshold[w.left >= 0] += np.float32(0.37)
+    w.feature[w.left >= 0, 0] = rng2.integers(0, 12, int((w.left >= 0).sum()))
+img1 = synth_image(1080, 1920, 99)
+for label, no_ranks in (("float32 pyramid", True), ("rank pyramid (union table)", False)):
+    E._NO_RANKS = no_ranks
+    for _ in range(4):
+        out = wb.detect(img1, M1, M2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 30
+    for _ in range(n):
+        out = wb.detect(img1, M1, M2)
+    dt = (time.perf_counter() - t0) / n
+    print(f"waldboost.detect, 2 models x 128 stages, 1080p, {label:28s}: {dt * 1e3:7.3f} ms per call, {len(out)} boxes")
+E._NO_RANKS = False

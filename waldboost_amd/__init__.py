@@ -46,24 +46,30 @@ def detect(image, *models, channel_opts=None, response_scale=None):
     if eng.plan.n_levels == 0:
         return concatenate([], ["scores", "label"])
     eng.load_images(image)
-    eng.run_channels()
-    res = [m.scan_engine(eng) for m in models]
-    parts = []
-    for lv in range(eng.plan.n_levels):
-        for k, r in enumerate(res):
-            sel = r["level"] == lv
-            if not sel.any():
-                continue
-            b = Boxes(r["boxes"][sel])
-            b.set_field("scores", r["scores"][sel] * response_scale[k])
-            b.set_field("label", np.full(int(sel.sum()), k, dtype=np.int64))
-            parts.append(b)
-    if not parts:
-        out = Boxes(np.empty((0, 4), "f"))
-        out.set_field("scores", np.empty(0, "f"))
-        out.set_field("label", np.empty(0, np.int64))
-        return out
-    return concatenate(parts, ["scores", "label"])
+    # one pyramid for all models: as threshold ranks of the UNION of their thresholds (one byte per value, the byte-tile
+    # cascade) when that union fits a rank table, as float32 channels otherwise
+    group = None
+    if spec.key == "grad_hist" and not _engine._NO_RANKS and all(m.shape[2] == spec.n_channels for m in models):
+        group = _engine.rank_group([m.device_cascade() for m in models])
+    if group is not None:
+        eng.run_channels(rank_dm=group.views[0], floats=False)
+        res = [m.scan_engine(eng, view=v) for m, v in zip(models, group.views)]
+    else:
+        eng.run_channels()
+        res = [m.scan_engine(eng) for m in models]
+    # level-major, then model, then row-major: every model's result is ordered by (level, r, c) already, so ONE stable sort
+    # by (level, model) gives the reference's nested-loop order (a Python loop over levels x models building Boxes was
+    # 0.8 ms of a 1.1 ms call)
+    K = len(models)
+    level = np.concatenate([r["level"] for r in res]).astype(np.int64)
+    label = np.concatenate([np.full(r["level"].size, k, np.int64) for k, r in enumerate(res)])
+    order = np.argsort(level * K + label, kind="stable")
+    boxes = np.concatenate([r["boxes"] for r in res])[order]
+    scores = np.concatenate([r["scores"] * response_scale[k] for k, r in enumerate(res)])[order]
+    out = Boxes(boxes.reshape(-1, 4).astype(np.float32, copy=False))
+    out.set_field("scores", scores.astype(np.float32, copy=False))
+    out.set_field("label", label[order])
+    return out
 
 
 default_channel_opts = dict(shrink=2, n_per_oct=8, smooth=1, channels=channels.grad_hist)

@@ -56,6 +56,9 @@ SYMBOLS = {
     "wb_model_info": (C.c_int, [_P, C.POINTER(WbModelInfo)]),
     "wb_model_specialize": (C.c_int, [_P, C.c_int]),
     "wb_jit_compile_check": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int64)]),
+    "wb_rankgroup_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(_P)]),
+    "wb_rankgroup_model": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "wb_rankgroup_destroy": (C.c_int, [_P]),
     "wb_cascade_launch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P,
                                     C.c_uint32, _P]),
     "wb_tree_eval_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P, _P, _P, _P, _P,

@@ -89,6 +89,83 @@ void fill(const TreeView &t, int node, int ci, int d, int D, int rows, int pitch
     fill<BYTES>(t, t.right[node], 2 * ci + 2, d + 1, D, rows, pitch, C, off, thr, pred);
 }
 
+
+// Rank tables of a SET of cascades (one model, or the members of a WbRankGroup): per channel the sorted distinct
+// thresholds of every internal node, the linear cell grid over them and the per-cell base counts (wb_common.h).
+struct RankTables {
+    std::vector<float> S[4];
+    float k[4], b[4];
+    int K = 1;
+    std::vector<uint8_t> lut;      // float S[4][WB_BIN_SLOTS], then uint8 base[4][WB_BIN_CELLS]
+};
+
+bool build_rank_tables(const std::vector<const std::vector<TreeView> *> &sets, RankTables &rt) {
+    const int N = WB_BIN_CELLS;
+    for (const std::vector<TreeView> *trees : sets)
+        for (const TreeView &t : *trees)
+            for (int i = 0; i < t.k; ++i)
+                if (t.left[i] >= 0 && t.threshold[i] == t.threshold[i]) {
+                    if (t.feature[i * 3 + 2] >= 4) return false;
+                    rt.S[t.feature[i * 3 + 2]].push_back(t.threshold[i]);
+                }
+    for (int c = 0; c < 4; ++c) {
+        std::sort(rt.S[c].begin(), rt.S[c].end());
+        rt.S[c].erase(std::unique(rt.S[c].begin(), rt.S[c].end()), rt.S[c].end());     // (== merges -0.0 and 0.0)
+        if ((int)rt.S[c].size() > WB_BIN_MAX) return false;
+    }
+    rt.lut.assign((size_t)4 * WB_BIN_SLOTS * 4 + (size_t)4 * N, 0);
+    float *Stab = reinterpret_cast<float *>(rt.lut.data());
+    uint8_t *base = rt.lut.data() + 4 * WB_BIN_SLOTS * 4;
+    rt.K = 1;
+    for (int c = 0; c < 4; ++c) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (float v : rt.S[c])
+            if (isfinite(v)) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
+        double k = 1.0, b = 1.0;
+        if (hi > lo) k = (double)(N - 2) / ((double)hi - (double)lo);
+        if (lo <= hi) b = 1.0 - (double)lo * k;
+        rt.k[c] = (float)k;
+        rt.b[c] = (float)b;
+        if (!(isfinite(rt.k[c]) && isfinite(rt.b[c]) && rt.k[c] > 0.0f)) return false;
+        std::vector<int> cnt((size_t)N, 0);
+        for (float v : rt.S[c]) cnt[bin_cell(v, rt.k[c], rt.b[c], N)]++;    // non-decreasing in v
+        int run = 0;
+        for (int j = 0; j < N; ++j) {
+            base[(size_t)c * N + j] = (uint8_t)run;
+            run += cnt[j];
+            if (cnt[j] > rt.K) rt.K = cnt[j];
+        }
+        for (int j = 0; j < WB_BIN_SLOTS; ++j) Stab[c * WB_BIN_SLOTS + j] = j < (int)rt.S[c].size() ? rt.S[c][j] : INFINITY;
+    }
+    return rt.K <= 16;
+}
+
+// rank[node] = index of the node's threshold in its channel's table (-1: leaf or NaN threshold); sets TreeView::rank
+void assign_ranks(std::vector<TreeView> &trees, const int32_t *node_off, const RankTables &rt, std::vector<int32_t> &rank) {
+    for (size_t s = 0; s < trees.size(); ++s) {
+        for (int i = 0; i < trees[s].k; ++i) {
+            const float th = trees[s].threshold[i];
+            if (trees[s].left[i] < 0 || th != th) continue;
+            const std::vector<float> &v = rt.S[trees[s].feature[i * 3 + 2]];
+            rank[(size_t)node_off[s] + i] = (int32_t)(std::lower_bound(v.begin(), v.end(), th) - v.begin());
+        }
+        trees[s].rank = rank.data() + node_off[s];
+    }
+}
+
+// the stage records of a cascade for byte tiles of threshold ranks (fill<2>): (n_stages + G) records of SD dwords
+void pack_rank_stages(const std::vector<TreeView> &trees, const float *theta, int D, int rows, int pitch, int C, int SD, int G,
+                      std::vector<int32_t> &packed) {
+    const int NI = (1 << D) - 1, NL = 1 << D, n_stages = (int)trees.size();
+    packed.assign((size_t)(n_stages + G) * SD, 0);
+    for (int s = n_stages; s < n_stages + G; ++s) reinterpret_cast<float *>(packed.data() + (size_t)s * SD)[2 * NI + NL] = -INFINITY;
+    for (int s = 0; s < n_stages; ++s) {
+        int32_t *rec = packed.data() + (size_t)s * SD;
+        fill<2>(trees[s], 0, 0, 0, D, rows, pitch, C, rec, reinterpret_cast<float *>(rec + NI), reinterpret_cast<float *>(rec + 2 * NI));
+        reinterpret_cast<float *>(rec)[2 * NI + NL] = theta[s];
+    }
+}
+
 }  // namespace
 
 extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint8_t *feature,
@@ -206,66 +283,22 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
 
     // ---- rank tables for float32 channels (wb_common.h: WbModel::bin_*): sorted distinct thresholds per channel
     std::vector<int32_t> rank((size_t)(n_stages ? node_off[n_stages] : 0), -1);
-    std::vector<uint8_t> lut;
+    RankTables rt;
     {
-        const int N = WB_BIN_CELLS;
-        bool ok = C == 4 && n_stages > 0 && getenv("WB_NO_RANKS") == nullptr;
-        std::vector<float> S[4];
-        if (ok) {
-            for (int s = 0; s < n_stages; ++s)
-                for (int i = 0; i < trees[s].k; ++i)
-                    if (trees[s].left[i] >= 0 && trees[s].threshold[i] == trees[s].threshold[i])
-                        S[trees[s].feature[i * 3 + 2]].push_back(trees[s].threshold[i]);
-            for (int c = 0; c < 4 && ok; ++c) {
-                std::sort(S[c].begin(), S[c].end());
-                S[c].erase(std::unique(S[c].begin(), S[c].end()), S[c].end());     // (== merges -0.0 and 0.0)
-                ok = (int)S[c].size() <= WB_BIN_MAX;
-            }
-        }
-        int K = 1;
-        if (ok) {
-            lut.assign((size_t)4 * WB_BIN_SLOTS * 4 + (size_t)4 * N, 0);
-            float *Stab = reinterpret_cast<float *>(lut.data());
-            uint8_t *base = lut.data() + 4 * WB_BIN_SLOTS * 4;
-            for (int c = 0; c < 4 && ok; ++c) {
-                float lo = INFINITY, hi = -INFINITY;
-                for (float v : S[c])
-                    if (isfinite(v)) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
-                double k = 1.0, b = 1.0;
-                if (hi > lo) k = (double)(N - 2) / ((double)hi - (double)lo);
-                if (lo <= hi) b = 1.0 - (double)lo * k;
-                M->bin_k[c] = (float)k;
-                M->bin_b[c] = (float)b;
-                ok = isfinite(M->bin_k[c]) && isfinite(M->bin_b[c]) && M->bin_k[c] > 0.0f;
-                if (!ok) break;
-                std::vector<int> cnt((size_t)N, 0);
-                for (float v : S[c]) cnt[bin_cell(v, M->bin_k[c], M->bin_b[c], N)]++;    // non-decreasing in v
-                int run = 0;
-                for (int j = 0; j < N; ++j) {
-                    base[(size_t)c * N + j] = (uint8_t)run;
-                    run += cnt[j];
-                    if (cnt[j] > K) K = cnt[j];
-                }
-                for (int j = 0; j < WB_BIN_SLOTS; ++j) Stab[c * WB_BIN_SLOTS + j] = j < (int)S[c].size() ? S[c][j] : INFINITY;
-            }
-            ok = ok && K <= 16;
-        }
-        if (ok) {
-            for (int s = 0; s < n_stages; ++s) {
-                for (int i = 0; i < trees[s].k; ++i) {
-                    const float th = trees[s].threshold[i];
-                    if (trees[s].left[i] < 0 || th != th) continue;
-                    const std::vector<float> &v = S[trees[s].feature[i * 3 + 2]];
-                    rank[(size_t)node_off[s] + i] = (int32_t)(std::lower_bound(v.begin(), v.end(), th) - v.begin());
-                }
-                trees[s].rank = rank.data() + node_off[s];
-            }
+        std::vector<const std::vector<TreeView> *> all = {&trees};
+        if (C == 4 && n_stages > 0 && getenv("WB_NO_RANKS") == nullptr && build_rank_tables(all, rt)) {
+            assign_ranks(trees, node_off, rt, rank);
             M->bin_ok = 1;
-            M->bin_cells = N;
-            M->bin_iters = K;
-            M->bin_lut_vec = (int)(lut.size() / 16);
+            M->bin_cells = WB_BIN_CELLS;
+            M->bin_iters = rt.K;
+            M->bin_lut_vec = (int)(rt.lut.size() / 16);
+            for (int c = 0; c < 4; ++c) {
+                M->bin_k[c] = rt.k[c];
+                M->bin_b[c] = rt.b[c];
+            }
         }
     }
+    const std::vector<uint8_t> &lut = rt.lut;
 
     // ---- pack and upload the stage records
     const int NI = (1 << D) - 1, NL = 1 << D, SD = M->stage_dwords;
@@ -299,6 +332,23 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
             for (int mode = 0; mode < 3; ++mode) fwrite(packs[mode].data(), 4, packs[mode].size(), f);
             fclose(f);
         }
+    }
+    {   // host copy of the trees as the caller gave them (wb_rankgroup_create)
+        const int n_nodes = n_stages ? node_off[n_stages] : 0;
+        auto dup = [](const void *src, size_t bytes) {
+            void *p = malloc(bytes ? bytes : 4);
+            if (bytes) memcpy(p, src, bytes);
+            return p;
+        };
+        const int32_t zero = 0;
+        M->n_nodes = n_nodes;
+        M->h_node_off = static_cast<int32_t *>(dup(n_stages ? node_off : &zero, (size_t)(n_stages + 1) * 4));
+        M->h_feature = static_cast<uint8_t *>(dup(feature, (size_t)n_nodes * 3));
+        M->h_threshold = static_cast<float *>(dup(threshold, (size_t)n_nodes * 4));
+        M->h_prediction = static_cast<float *>(dup(prediction, (size_t)n_nodes * 4));
+        M->h_left = static_cast<int8_t *>(dup(left, (size_t)n_nodes));
+        M->h_right = static_cast<int8_t *>(dup(right, (size_t)n_nodes));
+        M->h_theta = static_cast<float *>(dup(theta, (size_t)n_stages * 4));
     }
     M->stage_words = packs[1].size();
     M->stages_u8_host = static_cast<int32_t *>(malloc(packs[1].size() * 4 + 4));
@@ -336,6 +386,12 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
 
 extern "C" int wb_model_destroy(WbModel *model) {
     if (!model) return WB_OK;
+    if (model->proxy) {
+        wb_set_error("wb_model_destroy: this handle is a member view of a rank group (wb_rankgroup_destroy frees it)");
+        return WB_ERR_INVALID;
+    }
+    void *h[] = {model->h_node_off, model->h_feature, model->h_threshold, model->h_prediction, model->h_left, model->h_right, model->h_theta};
+    for (void *p : h) free(p);
     if (model->stages_dev) (void)hipFree(model->stages_dev);
     if (model->stages_u8_dev) (void)hipFree(model->stages_u8_dev);
     if (model->stages_bin_dev) (void)hipFree(model->stages_bin_dev);
@@ -389,4 +445,101 @@ extern "C" int wb_model_specialize(WbModel *model, int chn_dtype) {
     }
     return wb_jit_get(ranks ? model->stages_bin_host : model->stages_u8_host, model->stage_words, model->n_stages,
                       model->depth, model->rpw, model->waves, model->C, model->lds_rows, model->lds_pitch, slot);
+}
+
+
+// -------------------------------------------------------------------------------------------
+// Several cascades scanning ONE pyramid of threshold ranks (reference waldboost/__init__.py:120-124: detect(image,
+// *models) computes the channels once): the rank table of every channel is built from the UNION of the members'
+// thresholds -- `v <= S_k  <=>  rank(v) <= k` holds for any sorted superset of a model's thresholds -- and every member
+// gets stage records whose thresholds index that union.  A member is handed out as a VIEW of its model: a WbModel that
+// shares every pointer with it except the rank tables, usable wherever a model is (wb_channels_launch's rank_model -- any
+// member: they hold the same table --, wb_cascade_launch with WB_DTYPE_RANK8, wb_model_specialize, wb_model_info).
+struct WbRankGroup {
+    int n;
+    std::vector<WbModel *> views;
+    uint8_t *lut_dev;
+};
+
+extern "C" int wb_rankgroup_destroy(WbRankGroup *g) {
+    if (!g) return WB_OK;
+    for (WbModel *v : g->views) {
+        if (!v) continue;
+        if (v->stages_bin_dev) (void)hipFree(v->stages_bin_dev);
+        free(v->stages_bin_host);
+        delete v;
+    }
+    if (g->lut_dev) (void)hipFree(g->lut_dev);
+    delete g;
+    return WB_OK;
+}
+
+extern "C" int wb_rankgroup_create(const WbModel *const *models, int n, WbRankGroup **out) {
+    WB_REQUIRE(out, "wb_rankgroup_create: out is null");
+    *out = nullptr;
+    WB_REQUIRE(models && n >= 1 && n <= 64, "wb_rankgroup_create: 1..64 models");
+    std::vector<std::vector<TreeView>> trees((size_t)n);
+    std::vector<const std::vector<TreeView> *> sets;
+    for (int i = 0; i < n; ++i) {
+        const WbModel *m = models[i];
+        WB_REQUIRE(m && !m->proxy, "wb_rankgroup_create: model %d is null or itself a member view", i);
+        if (m->generic || m->C != 4 || m->n_stages == 0) {
+            wb_set_error("wb_rankgroup_create: model %d has no rank form (node-walk kernel, %d channels, %d stages)", i, m->C, m->n_stages);
+            return WB_ERR_UNSUPPORTED;
+        }
+        for (int s = 0; s < m->n_stages; ++s) {
+            const int o = m->h_node_off[s];
+            trees[i].push_back(TreeView{m->h_node_off[s + 1] - o, m->h_feature + (size_t)o * 3, m->h_threshold + o, m->h_left + o,
+                                        m->h_right + o, m->h_prediction + o, nullptr});
+        }
+        sets.push_back(&trees[i]);
+    }
+    RankTables rt;
+    if (getenv("WB_NO_RANKS") != nullptr || !build_rank_tables(sets, rt)) {
+        wb_set_error("wb_rankgroup_create: the models' thresholds do not fit one rank table (more than %d distinct per channel)", WB_BIN_MAX);
+        return WB_ERR_UNSUPPORTED;
+    }
+    WbRankGroup *g = new WbRankGroup();
+    g->n = n;
+    g->lut_dev = nullptr;
+    g->views.assign((size_t)n, nullptr);
+    hipError_t e = hipMalloc((void **)&g->lut_dev, rt.lut.size());
+    if (e == hipSuccess) e = hipMemcpy(g->lut_dev, rt.lut.data(), rt.lut.size(), hipMemcpyHostToDevice);
+    for (int i = 0; i < n && e == hipSuccess; ++i) {
+        const WbModel *m = models[i];
+        std::vector<int32_t> rank((size_t)m->n_nodes, -1), packed;
+        assign_ranks(trees[i], m->h_node_off, rt, rank);
+        pack_rank_stages(trees[i], m->h_theta, m->depth, m->lds_rows, m->lds_pitch, m->C, m->stage_dwords, wb_cascade_group(m->depth), packed);
+        WbModel *v = new WbModel(*m);                       // shares every device / host pointer of the model ...
+        v->proxy = 1;
+        v->bin_ok = 1;                                      // ... but the rank tables: the group's
+        v->bin_cells = WB_BIN_CELLS;
+        v->bin_iters = rt.K;
+        v->bin_lut_vec = (int)(rt.lut.size() / 16);
+        for (int c = 0; c < 4; ++c) {
+            v->bin_k[c] = rt.k[c];
+            v->bin_b[c] = rt.b[c];
+        }
+        v->bin_lut_dev = g->lut_dev;
+        v->jit_bin = nullptr;                               // (a specialised kernel bakes the thresholds' indices: per view)
+        v->stages_bin_dev = nullptr;
+        v->stages_bin_host = static_cast<int32_t *>(malloc(packed.size() * 4 + 4));
+        memcpy(v->stages_bin_host, packed.data(), packed.size() * 4);
+        g->views[(size_t)i] = v;
+        e = hipMalloc((void **)&v->stages_bin_dev, packed.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(v->stages_bin_dev, packed.data(), packed.size() * 4, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        wb_set_error("wb_rankgroup_create: uploading the tables failed: %s", hipGetErrorString(e));
+        wb_rankgroup_destroy(g);
+        return WB_ERR_HIP;
+    }
+    *out = g;
+    return WB_OK;
+}
+
+extern "C" int wb_rankgroup_model(WbRankGroup *group, int i, WbModel **view) {
+    WB_REQUIRE(group && view && i >= 0 && i < group->n, "wb_rankgroup_model: bad argument");
+    *view = group->views[(size_t)i];
+    return WB_OK;
 }

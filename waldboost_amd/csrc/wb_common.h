@@ -86,6 +86,13 @@ struct WbModel {
     int bin_lut_vec;            // size of the table block in 16-byte units
     uint8_t *bin_lut_dev;       // float S[4][256] (sorted thresholds, +inf padded), then uint8 base[4][N]
     int32_t *stages_bin_dev;    // stage records for the binned tile: byte-tile offsets, thresholds = ranks
+    // host copy of the caller's tree arrays (wb_rankgroup_create derives stage records for a shared rank table from them)
+    int n_nodes;
+    int32_t *h_node_off;        // [n_stages + 1]
+    uint8_t *h_feature;         // [n_nodes][3]
+    float *h_threshold, *h_prediction, *h_theta;
+    int8_t *h_left, *h_right;
+    int proxy;                  // 1 = a member view of a WbRankGroup: shares every pointer but the rank tables with its model
     // model-specialised kernels (wb_jit.hip, wb_model_specialize): hipFunction_t per byte-tile stage table, or null
     int32_t *stages_u8_host, *stages_bin_host;   // host copies of the two byte-tile tables the generator bakes in
     size_t stage_words;                          // (n_stages + G) * stage_dwords

@@ -120,16 +120,33 @@ class DeviceCascade:
                                       vp(th), m, n, Cc, C.byref(h)), "wb_model_create")
         self.handle = h
         self._lib = lib
+        self._owned = True
+        self._scans = {}                 # byte-tile scans so far, per channel dtype code
+        self._jit_failed = set()
+        self.rank_key = self             # whose rank tables this cascade scans: its own (a RankGroup's for a member view)
+        self._read_info()
+
+    def _read_info(self):
         info = nat.WbModelInfo()
-        nat.check(lib.wb_model_info(h, C.byref(info)), "wb_model_info")
+        nat.check(self._lib.wb_model_info(self.handle, C.byref(info)), "wb_model_info")
         self.n_stages, self.depth = info.n_stages, info.depth
         self.m, self.n, self.C = info.m, info.n, info.C
         self.tile_rows, self.tile_cols, self.lds_bytes = info.tile_rows, info.tile_cols, info.lds_bytes
         # the model's thresholds fit rank tables: the channel kernel can write float32 channels as one-byte ranks
         # (WB_DTYPE_RANK8) and the cascade scan them exactly as it would the floats, from a quarter of the bytes
         self.rank_ok = bool(info.rank_ok)
-        self._scans = {}                 # byte-tile scans so far, per channel dtype code
-        self._jit_failed = set()
+
+    @classmethod
+    def _view(cls, handle, group):
+        """A member view of a RankGroup: same interface, handle owned by the group."""
+        self = cls.__new__(cls)
+        self._lib = nat.load()
+        self.handle = handle
+        self._owned = False
+        self._scans, self._jit_failed = {}, set()
+        self.rank_key = group
+        self._read_info()
+        return self
 
     def specialized(self):
         """Which byte tiles have a model-specialised kernel loaded: subset of {WB_DTYPE_U8, WB_DTYPE_RANK8}."""
@@ -172,11 +189,57 @@ class DeviceCascade:
 
     def __del__(self):
         try:
-            if getattr(self, "handle", None):
+            if getattr(self, "handle", None) and self._owned:
                 self._lib.wb_model_destroy(self.handle)
                 self.handle = None
         except Exception:
             pass
+
+
+class RankGroup:
+    """Several cascades over ONE pyramid of threshold ranks (wb_rankgroup_create): the rank table of every channel is
+    built from the union of the members' thresholds; ``views[i]`` is member i as a DeviceCascade whose rank tables are the
+    group's.  Raises NotImplementedError when the union does not fit (more than 255 thresholds on a channel)."""
+
+    def __init__(self, cascades):
+        lib = nat.load()
+        self._lib = lib
+        self.members = list(cascades)                      # (the models must outlive the group)
+        arr = (C.c_void_p * len(self.members))(*[dm.handle.value for dm in self.members])
+        h = C.c_void_p()
+        nat.check(lib.wb_rankgroup_create(arr, len(self.members), C.byref(h)), "wb_rankgroup_create")
+        self.handle = h
+        self.views = []
+        for i in range(len(self.members)):
+            v = C.c_void_p()
+            nat.check(lib.wb_rankgroup_model(h, i, C.byref(v)), "wb_rankgroup_model")
+            self.views.append(DeviceCascade._view(v, self))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.wb_rankgroup_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+_GROUPS = {}
+
+
+def rank_group(cascades):
+    """The (cached) RankGroup of these cascades, or None when they cannot share a rank table."""
+    key = tuple(id(dm) for dm in cascades)
+    g = _GROUPS.get(key)
+    if g is None or (g and any(a is not b for a, b in zip(g.members, cascades))):
+        try:
+            g = RankGroup(cascades)
+        except NotImplementedError:
+            g = False
+        if len(_GROUPS) >= 8:
+            _GROUPS.pop(next(iter(_GROUPS)))
+        _GROUPS[key] = g
+    return g or None
 
 
 class DetBuffer:
@@ -413,7 +476,7 @@ class PyramidEngine:
                                               rank_dm.handle if rank_dm is not None else None,
                                               nat.ptr(self.rank if rank_dm is not None else None), self.chn_stride),
                   "wb_channels_launch")
-        self.rank_owner = rank_dm               # whose ranks self.rank holds (None: stale)
+        self.rank_owner = rank_dm.rank_key if rank_dm is not None else None      # whose ranks self.rank holds (None: stale)
 
     def launch_level(self, l):
         """The float/uint8 channels of ONE level of every resident image (after launch_octaves): what a lazy
@@ -452,7 +515,9 @@ class PyramidEngine:
                 dm=dm, n_tiles=int(tiles.size),
                 tiles=torch.from_numpy(tiles.view(np.uint8).copy()).to(self.dev) if tiles.size else None,
                 alive=alive)
-            self._casc = {key: stt}          # one cascade resident per engine
+            if len(self._casc) >= 4:         # a few cascades resident per engine (waldboost.detect scans several models)
+                self._casc.pop(next(iter(self._casc)))
+            self._casc[key] = stt
         return stt
 
     def launch_cascade(self, dm, ranks=False, stats=True):
@@ -461,7 +526,7 @@ class PyramidEngine:
         stt = self._casc_state(dm)
         if stt["n_tiles"] == 0:
             return stt
-        if ranks and self.rank_owner is not dm:
+        if ranks and self.rank_owner is not dm.rank_key:
             raise RuntimeError("the rank buffer does not hold this cascade's ranks (launch_channels(rank_dm=...) first)")
         dm.note_scan(nat.WB_DTYPE_RANK8 if ranks else self.spec.wb_dtype)
         nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.rank if ranks else self.chn),

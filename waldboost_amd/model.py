@@ -173,14 +173,15 @@ class Model:
         fin = eng.detect_run(dm)
         return self._collect(eng, dm, eng._casc_state(dm), _full, fin)
 
-    def scan_engine(self, eng):
+    def scan_engine(self, eng, view=None):
         """Run this cascade over the channel pyramid already resident in `eng` (channels computed
         by the caller: several models can share one pyramid, reference __init__.py:120-124).
-        Returns the same dict as detect_raw and updates n_loc / n_weak."""
+        view: this model's member view of a RankGroup whose threshold ranks `eng` holds (scan those instead of the
+        float32 channels).  Returns the same dict as detect_raw and updates n_loc / n_weak."""
         m, n, Cc = self.shape
         assert Cc == eng.spec.n_channels, f"Invalid number of channels. Expected {Cc} given {eng.spec.n_channels}."
-        dm = self.device_cascade()
-        return self._collect(eng, dm, eng.run_cascade(dm))
+        dm = view if view is not None else self.device_cascade()
+        return self._collect(eng, dm, eng.run_cascade(dm, ranks=view is not None))
 
     def _collect(self, eng, dm, stt, full=True, fin=False):
         """Results of the scan `stt` of image 0 of `eng`: the dict detect_raw returns; updates n_loc / n_weak.
