@@ -61,7 +61,7 @@ extern "C" {
  * model `v <= threshold` (training.py:92) is `rank(v) <= index(threshold)` for every float v, so the cascade
  * decides exactly as on the float32 channels while reading a quarter of the bytes.  Written by
  * wb_channels_launch(rank_model, rank), read by wb_cascade_launch(chn_dtype = WB_DTYPE_RANK8) with the SAME
- * model.  Available when the model has 4 channels and at most 255 distinct thresholds per channel
+ * model.  Available when the model has 4 channels and at most 254 distinct thresholds per channel
  * (WbModelInfo.rank_ok). */
 #define WB_DTYPE_RANK8 2
 /* Image buffers only: the other dtypes the reference's channel_pyramid accepts (channels.py:122 keeps
@@ -246,7 +246,7 @@ int wb_model_specialize(WbModel *model, int chn_dtype);
  * thresholds.  wb_rankgroup_model hands out member i as a VIEW of its model -- a WbModel handle owned by the group that
  * shares everything with the model but the rank tables; pass any view as wb_channels_launch's rank_model (they hold
  * the same table) and view i to wb_cascade_launch(WB_DTYPE_RANK8) / wb_model_specialize / wb_model_info.  The models
- * must outlive the group.  WB_ERR_UNSUPPORTED when a channel's union exceeds 255 thresholds or a member has no rank
+ * must outlive the group.  WB_ERR_UNSUPPORTED when a channel's union exceeds 254 thresholds or a member has no rank
  * form (node-walk models, C != 4): scan float32 channels then. */
 typedef struct WbRankGroup WbRankGroup;
 int wb_rankgroup_create(const WbModel *const *models, int n, WbRankGroup **out);

@@ -301,8 +301,10 @@ template <int S_, int TU_, int TV_, bool SMOOTH_, int NT_ = 256> struct TileGeom
 //      Ends without a barrier: the caller synchronises before reading R.
 template <typename T, typename G>
 __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &L, const T *src, const double mn,
-                                              const double mx, const int ry0, const int rx0, float *R,
+                                              const double mx, const int ry0, const int rx0, const int rh, float *R,
                                               unsigned char *uni, float4 *rowtab, const int tid) {
+    // rh <= RH: the tile rows that are needed (a tile on the bottom edge of its level uses fewer): wave-uniform, the
+    // strips below are cut from it
     constexpr int RH = G::RH, RW = G::RW, PROWS = G::PROWS, PPITCH = G::PPITCH, NT = G::NT, NW = G::NW;
     const Tap *__restrict__ rtap = a.taps + L.tap_off;      // row taps [nh], then column taps [nw]
     const Tap *__restrict__ ctap = rtap + L.nh;
@@ -358,7 +360,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
     for (int c = 0; c < NCS; ++c) tcs[c] = trl;
     if constexpr (sizeof(T) == 1) {
         int yf = ry0 < 0 ? 0 : (ry0 > L.nh - 1 ? L.nh - 1 : ry0);
-        int yl = ry0 + RH - 1; yl = yl < 0 ? 0 : (yl > L.nh - 1 ? L.nh - 1 : yl);
+        int yl = ry0 + rh - 1; yl = yl < 0 ? 0 : (yl > L.nh - 1 ? L.nh - 1 : yl);
         int xf = rx0 < 0 ? 0 : (rx0 > L.nw - 1 ? L.nw - 1 : rx0);
         int xl = rx0 + RW - 1; xl = xl < 0 ? 0 : (xl > L.nw - 1 ? L.nw - 1 : xl);
         // strict down-scale on both axes: every tap pair is (i0, i0 + 1), no mirroring (plan.axis_taps), and the
@@ -383,10 +385,10 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             tcs[c] = ctap[x];
         }
         {
-            constexpr int RS = (RH + NW - 1) / NW;              // rows of a wave's strip (see the row loop)
-            static_assert(RS <= 64, "one lane per row of the strip");
+            static_assert((RH + NW - 1) / NW <= 64, "one lane per row of the strip");
+            const int RS = (rh + NW - 1) / NW;                  // rows of a wave's strip (see the row loop)
             const int kl = wave * RS + lane;
-            int ly = ry0 + (kl < RH ? kl : RH - 1);
+            int ly = ry0 + (kl < rh ? kl : rh - 1);
             ly = ly < 0 ? 0 : (ly > L.nh - 1 ? L.nh - 1 : ly);
             trl = rtap[ly];
             int lx = rx0 + MAINW + (lane < LEFT ? lane : 0);
@@ -425,9 +427,9 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             // -- on gfx950 an fp32 add / multiply / fmac whose operands are all vector registers issues in 2 cycles,
             // with a scalar-register operand in 4 (tools/valu_class_probe.hip), and a v_readlane costs 4 as well
             {
-                constexpr int RS = (RH + NW - 1) / NW;
+                const int RS = (rh + NW - 1) / NW;
                 const int kl = wave * RS + lane;
-                if (lane < RS && kl < RH) rowtab[kl] = make_float4(__int_as_float((trl.i0 - r_lo) * PPITCH), (float)trl.w0, (float)trl.w1, 0.0f);
+                if (lane < RS && kl < rh) rowtab[kl] = make_float4(__int_as_float((trl.i0 - r_lo) * PPITCH), (float)trl.w0, (float)trl.w1, 0.0f);
             }
             if (LEFT > 0 && tid >= 64 && tid < 64 + LEFT)
                 rowtab[RH + tid - 64] = make_float4(__int_as_float(tleft.i0 - c_lo), (float)tleft.w0, (float)tleft.w1, 0.0f);
@@ -458,8 +460,8 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
 #define WB_CHAN_RB 2
 #endif
             constexpr int RB = WB_CHAN_RB;
-            constexpr int RS = (RH + NW - 1) / NW;
-            const int k_lo = wave * RS, k_hi = k_lo + RS < RH ? k_lo + RS : RH;
+            const int RS = (rh + NW - 1) / NW;
+            const int k_lo = wave * RS, k_hi = k_lo + RS < rh ? k_lo + RS : rh;
             float hprev[NCS];                     // horizontal interpolation of the patch row at byte offset o_prev,
             uint8_t pb[NCS][2];                   // and its two tap bytes (the exact redo wants them)
             int o_prev = -1;
@@ -578,13 +580,13 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
         // RB rows per pass: all their source loads are in flight before the first one is used
         // (one row at a time, the loop was a chain of RH/4 memory latencies per wave)
         constexpr int RB = sizeof(T) == 8 ? 2 : 5;             // (a double pixel is two registers)
-        for (int k0 = wave; k0 < RH; k0 += NW * RB) {
+        for (int k0 = wave; k0 < rh; k0 += NW * RB) {
             Tap tr[RB];
             T v00[RB][NCS], v01[RB][NCS], v10[RB][NCS], v11[RB][NCS];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 int k = k0 + NW * rb;
-                k = k < RH ? k : RH - 1;                                  // clamped, unconditional loads
+                k = k < rh ? k : rh - 1;                                  // clamped, unconditional loads
                 int y = ry0 + k;
                 y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
                 tr[rb] = rtap[__builtin_amdgcn_readfirstlane(y)];
@@ -617,14 +619,14 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                             out = Src<T>::finish(resample_f64((double)v00[rb][c], (double)v01[rb][c], (double)v10[rb][c],
                                                               (double)v11[rb][c], tr[rb], tc[c]), mn, mx, a.src_int);
                     }
-                    if (k < RH) R[k * RW + lane + 64 * c] = out;
+                    if (k < rh) R[k * RW + lane + 64 * c] = out;
                 }
             }
         }
     }
     WB_CSTAMP(3);
     if constexpr (LEFT > 0) {
-        for (int p = tid; p < RH * LEFT; p += NT) {
+        for (int p = tid; p < rh * LEFT; p += NT) {
             const int k = p / LEFT, q = MAINW + p - k * LEFT;
             int y = ry0 + k, x = rx0 + q;
             y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
@@ -692,14 +694,18 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 || S == 4 ? 1 : 4) void channels
     clip_range<T>(a, b, L.oct, mn, mx);
 
     const int ry0 = S * (u0 - HS) - 1, rx0 = S * (v0 - HS) - 1;
+    // a tile on the bottom edge of its level holds fewer than TU output rows: the shrunk rows (su_need) and resized
+    // rows (rh_need) behind them are all the steps below compute (7 % of the tiles' rows at 1080p lie past an edge)
+    const int vrows = L.u - u0 < TU ? L.u - u0 : TU;
+    const int su_need = vrows + 2 * HS, rh_need = S * su_need + 2;
     WB_CSTAMP(0);
-    resample_tile<T, G>(a, L, src, mn, mx, ry0, rx0, R, uni, rowtab, tid);
+    resample_tile<T, G>(a, L, src, mn, mx, ry0, rx0, rh_need, R, uni, rowtab, tid);
     __syncthreads();
     WB_CSTAMP(4);
     if (a.dbg & 1) return;
 
     // ---- step 2: gradients -> 4 oriented channels -> shrink, one shrunk pixel per iteration
-    for (int p = tid; p < SU * SV; p += NT) {
+    for (int p = tid; p < su_need * SV; p += NT) {
         int i = p / SV, j = p - i * SV;
         float pt[P][P];
 #pragma unroll
@@ -812,7 +818,13 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 || S == 4 ? 1 : 4) void channels
     const int j = tid % TV, i0 = (tid / TV) * RPT;
     const int sv = v0 + j;
     float o[RPT][4];
-    if constexpr (SMOOTH) {
+    // (64-wide tiles: a wave owns whole output rows, so on a bottom-edge tile the waves whose rows lie past the level
+    // skip the smooth and the ranks -- wave-uniform; they still meet the barrier below)
+    const bool live = TV != 64 || u0 + __builtin_amdgcn_readfirstlane(i0) < L.u;
+#pragma unroll
+    for (int y = 0; y < RPT; ++y) o[y][0] = o[y][1] = o[y][2] = o[y][3] = 0.0f;
+    if (!live) {
+    } else if constexpr (SMOOTH) {
         if (SEPARABLE && odd_values == 0) {
             // Every value of the tile is 0 or a float32 in [2^-3, 2^11): all partial sums of the nine
             // weighted terms are multiples of 2^-26 below 2^15 -- exact in fp64 in ANY order.  So the
@@ -885,20 +897,37 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 || S == 4 ? 1 : 4) void channels
         // all RPT x 4 values of the thread advance together: every step is RPT * 4 independent LDS lookups (one
         // value at a time, the 1 + K dependent lookups of each value were a chain of LDS latencies)
         uint32_t r[RPT][4];
-#pragma unroll
-        for (int y = 0; y < RPT; ++y)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) r[y][k] = base[k * WB_BIN_CELLS + wb_bin_cell(o[y][k], a.rank_k[k], a.rank_b[k])];
-        for (int i = 0; i < K; ++i) {
+        if (live) {
 #pragma unroll
             for (int y = 0; y < RPT; ++y)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) r[y][k] += o[y][k] > Sthr[k * WB_BIN_SLOTS + r[y][k]] ? 1u : 0u;
+                for (int k = 0; k < 4; ++k) r[y][k] = base[k * WB_BIN_CELLS + wb_bin_cell(o[y][k], a.rank_k[k], a.rank_b[k])];
+            if (K <= 2) {
+                // the usual case -- at most two thresholds share a cell: both candidates S[r], S[r + 1] come with ONE
+                // LDS read (they are neighbours) and are compared independently: S is sorted, so the second test only
+                // passes where the first does; a threshold of a higher cell, or the +inf padding, never passes
+                // (r + 1 <= WB_BIN_MAX stays inside the channel's table)
+#pragma unroll
+                for (int y = 0; y < RPT; ++y)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float *sp = Sthr + k * WB_BIN_SLOTS + r[y][k];
+                        const float s0 = sp[0], s1 = sp[1];
+                        r[y][k] += (o[y][k] > s0 ? 1u : 0u) + (o[y][k] > s1 ? 1u : 0u);
+                    }
+            } else {
+                for (int i = 0; i < K; ++i) {
+#pragma unroll
+                    for (int y = 0; y < RPT; ++y)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) r[y][k] += o[y][k] > Sthr[k * WB_BIN_SLOTS + r[y][k]] ? 1u : 0u;
+                }
+            }
         }
 #pragma unroll
         for (int y = 0; y < RPT; ++y) {
             const int su = u0 + i0 + y;
-            if (su >= L.u || sv >= L.v || (a.dbg & 4)) continue;
+            if (!live || su >= L.u || sv >= L.v || (a.dbg & 4)) continue;
             uint32_t w = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -943,7 +972,7 @@ __global__ __launch_bounds__(256) void channels_u1_kernel(ChanArgs a) {
     double mn, mx;
     clip_range<T>(a, b, L.oct, mn, mx);
     const int ry0 = S * (u0 - HS) - 1, rx0 = S * (v0 - HS) - 1;
-    resample_tile<T, G>(a, L, src, mn, mx, ry0, rx0, R, uni, rowtab, tid);
+    resample_tile<T, G>(a, L, src, mn, mx, ry0, rx0, RH, R, uni, rowtab, tid);
     __syncthreads();
     if (a.dbg & 1) return;
 

@@ -47,7 +47,9 @@ __host__ __device__ inline float wb_key_f32(uint32_t k) {
 // ---- cascade geometry ----
 #define WB_CASC_TC 64        // windows per tile row = one per lane
 #define WB_CASC_MAX_DEPTH 3
-#define WB_BIN_MAX 255       // distinct thresholds per channel a binned tile can rank in one byte (255 = NaN pixel)
+#define WB_BIN_MAX 254       // distinct thresholds per channel a binned tile can rank in one byte: ranks 0..254, 255 = NaN
+                             // pixel; S[254] and S[255] of a channel's table are then always the +inf padding, so the
+                             // channel kernel may read S[r] and S[r + 1] together for every rank r <= 254
 #define WB_BIN_SLOTS 256     // entries of a channel's sorted threshold table
 #define WB_BIN_CELLS 2048    // cells of a channel's lookup grid
 #define WB_BIN_LUT_BYTES (4 * WB_BIN_SLOTS * 4 + 4 * WB_BIN_CELLS)   // float S[4][256], then uint8 base[4][N]
