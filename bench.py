@@ -184,6 +184,8 @@ def main():
                          "the launch path on a machine without GPUs")
     args = ap.parse_args()
 
+    if args.no_jit:
+        os.environ["WB_CASC_JIT"] = "0"                       # (also the engine's own after-a-few-scans policy; children inherit it)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))

@@ -14,6 +14,8 @@ for path in args.dirs:
         for row in csv.DictReader(open(f)):
             m = re.search(r"(\w+_kernel)", row["Kernel_Name"])
             k = m.group(1) if m else row["Kernel_Name"][:50]
+            if "wb_casc_jit" in row["Kernel_Name"]:
+                k = "cascade_tile_kernel"                    # (the model-specialised build of the tile kernel)
             if only and k not in only:
                 continue
             acc[k][row["Counter_Name"]] += float(row["Counter_Value"])

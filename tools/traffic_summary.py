@@ -7,8 +7,9 @@ for path in sys.argv[1:]:
     for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             m = re.search(r"(\w+_kernel)", row["Kernel_Name"])
-            if m:
-                vals[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            name = "cascade_tile_kernel" if "wb_casc_jit" in row["Kernel_Name"] else (m.group(1) if m else None)   # (the model-specialised build of the tile kernel)
+            if name:
+                vals[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {"_note": __doc__.strip()}
 for k, c in vals.items():
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
