@@ -76,6 +76,13 @@ extern "C" {
 #define WB_DTYPE_U16 6
 #define WB_DTYPE_I32 7
 #define WB_DTYPE_U32 8
+/* int64 / uint64 images whose values are exact in float64 (|v| < 2^51: the caller checks; their 2x2 sums then neither
+ * round nor wrap), bool images (NumPy adds bools with logical OR, so a pooled pixel is "any of the four"; the resize
+ * result is cast back with != 0) and float16 images (every add of avg_pool_2 and the cast back round to binary16). */
+#define WB_DTYPE_I64 9
+#define WB_DTYPE_U64 10
+#define WB_DTYPE_BOOL 11
+#define WB_DTYPE_F16 12
 
 /* Channel functions (channel_opts["channels"] of the reference) the channel kernel implements:
  *   WB_CHN_GRAD_HIST       waldboost.channels.grad_hist (n_bins=4)    4 x float32  channels.py:40-52
@@ -209,13 +216,16 @@ int wb_channels_launch(void *stream, const void *img, int64_t img_stride, const 
  * (reference channels.py:40-52 grad_hist(image, n_bins, full, bias) and :30-37 grad_mag(image, norm, eps); with
  * their default arguments, and inside channel_pyramid, they run in wb_channels_launch).
  *   wb_grad_hist_launch  cs_sn HOST double[2*n_bins]: cos(theta_k) then sin(theta_k) of np.linspace(0, pi or 2*pi,
- *                        n_bins+1)[:-1]; bias as float32 (a Python scalar is one under NumPy-2 promotion);
- *                        out dev float32 [H][W][n_bins]
+ *                        n_bins+1)[:-1]; wide = 0: bias is a float32 value (a Python scalar is one under NumPy-2
+ *                        promotion), out dev float32 [H][W][n_bins]; wide = 1: bias is a float64 / int64 NumPy scalar --
+ *                        |chns| - bias and everything after it are float64, out dev float64 [H][W][n_bins]
  *   wb_grad_mag_launch   n_taps = 0: the plain magnitude (norm None or <= 1); else taps HOST float32[n_taps] =
- *                        triangle_kernel(norm), eps float32, scratch dev float32[2*H*W]; out dev float32 [H][W] */
-int wb_grad_hist_launch(void *stream, const float *img, int H, int W, int n_bins, int full, float bias,
-                        const double *cs_sn, float *out);
-int wb_grad_mag_launch(void *stream, const float *img, int H, int W, int n_taps, const float *taps, float eps,
+ *                        triangle_kernel(norm), scratch dev float32[2*H*W]; out dev float32 [H][W]; wide = 0: eps is a
+ *                        float32 value, mag / (norm + eps) in float32; wide = 1: eps is a float64 NumPy scalar -- the
+ *                        in-place `mag /= norm + eps` divides in float64 and rounds once to float32 */
+int wb_grad_hist_launch(void *stream, const float *img, int H, int W, int n_bins, int full, double bias, int wide,
+                        const double *cs_sn, void *out);
+int wb_grad_mag_launch(void *stream, const float *img, int H, int W, int n_taps, const float *taps, double eps, int wide,
                        float *scratch, float *out);
 
 /* Build the device-side cascade from the reference's tree arrays (all HOST pointers).

@@ -217,7 +217,8 @@ def grad_hist(image, n_bins=4, full=False, bias=0):
     gy64 = gy.astype(np.float64)
     for i, (c, s) in enumerate(zip(cs, sn)):
         chns[..., i] = gx64 * c - gy64 * s
-    value = np.fmax(np.abs(chns) - np.float32(bias), np.float32(0))
+    # (NumPy-2 promotion: a Python scalar or a float32 leaves this float32, a float64 / int64 NumPy scalar makes it float64)
+    value = np.fmax(np.abs(chns) - (bias if isinstance(bias, np.generic) else np.float32(bias)), 0)
     return np.sign(chns) * value if full else value
 
 
@@ -256,7 +257,8 @@ def grad_mag(image, norm=5, eps=1e-3):
     if norm is not None and norm > 1:
         H = triangle_kernel(norm)
         nrm = _conv_sym(_conv_sym(mag, H, 0), H, 1)
-        mag = mag / (nrm + np.float32(eps))
+        # (`mag /= norm + eps`: with a float64 NumPy eps the quotient is float64, cast back into the float32 array)
+        mag = (mag / (nrm + (eps if isinstance(eps, np.generic) else np.float32(eps)))).astype(np.float32)
     return mag[..., None]
 
 

@@ -272,9 +272,24 @@ def test_channel_functions_with_arguments_vs_reference_fixture(case):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
-def test_channel_function_arguments_that_would_change_the_result_dtype():
+def test_channel_function_arguments_that_change_the_arithmetic_dtype():
+    """A float64 / int64 NumPy scalar is a strong type under NumPy-2 promotion: `np.abs(chns) - bias` (reference
+    channels.py:51) then yields a float64 array, `mag /= norm + eps` (:36) divides in float64 and rounds once back to
+    float32.  The oracle evaluates the reference's own expressions."""
     import waldboost_amd as wb
+    from waldboost_amd.synth import synth_image
+    for img in (synth_image(61, 83, 31), synth_image(50, 70, 32, np.float32)):
+        for kw in (dict(bias=np.float64(1.25)), dict(n_bins=6, full=True, bias=np.float64(0.3)), dict(n_bins=3, bias=np.int64(2)),
+                   dict(bias=np.float64(0.0))):
+            got, ref = wb.channels.grad_hist(img, **kw), orc.grad_hist(img, **kw)
+            assert got.dtype == ref.dtype == np.float64 and got.shape == ref.shape
+            assert np.array_equal(got.view(np.uint64), ref.view(np.uint64)), kw
+        for kw in (dict(eps=np.float64(1e-3)), dict(norm=3, eps=np.float64(0.01))):
+            got, ref = wb.channels.grad_mag(img, **kw), orc.grad_mag(img, **kw)
+            assert got.dtype == ref.dtype == np.float32 and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), kw
+        narrow = wb.channels.grad_mag(img, norm=3, eps=0.01)
+        assert not np.array_equal(narrow, wb.channels.grad_mag(img, norm=3, eps=np.float64(0.01))) or img.dtype == np.uint8
     img = np.zeros((20, 30), np.uint8)
+    assert wb.channels.grad_hist(img, n_bins=3, bias=np.float32(1.0)).dtype == np.float32
     with pytest.raises(NotImplementedError):
-        wb.channels.grad_hist(img, bias=np.float64(1.0))          # float64 scalar: the reference's result is float64
-    assert wb.channels.grad_hist(img, n_bins=3, bias=np.float32(1.0)).shape == (20, 30, 3)
+        wb.channels.grad_hist(img, bias=np.complex64(1.0))

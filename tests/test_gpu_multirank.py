@@ -90,7 +90,7 @@ def _edge_worker(rank, world, port, q):
         tiny = torch.zeros((hi - lo, 6, 40), dtype=torch.float64, device="cuda")  # h < 8: no octave, no level
         det0, alive0, total0 = detect_sharded(M, tiny)
         try:
-            detect_sharded(M, torch.zeros((1, 200, 264), dtype=torch.float16, device="cuda"))
+            detect_sharded(M, torch.zeros((1, 200, 264), dtype=torch.complex64, device="cuda"))
             unsupported = "no error"
         except NotImplementedError:
             unsupported = "NotImplementedError"

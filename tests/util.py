@@ -58,14 +58,16 @@ def f2_cases():
 
 
 def dtype_cases():
-    """Small grad_hist pyramids of float64 / integer images (tests/golden/make_golden_dtypes.py)."""
-    with open(os.path.join(GOLDEN, "golden_meta_dtypes.json")) as f:
-        meta = json.load(f)["cases"]
-    z = np.load(os.path.join(GOLDEN, "pyramids_dtypes.npz"))
-    for name, info in meta.items():
-        img = z[f"{name}/image"]
-        levels = [z[f"{name}/L{i}"] for i in range(info["n_levels"])]
-        yield name, img, info, levels
+    """Small grad_hist pyramids of float64 / integer / float16 / bool images (tests/golden/make_golden_dtypes.py,
+    make_golden_dtypes2.py)."""
+    for stem in ("dtypes", "dtypes2"):
+        with open(os.path.join(GOLDEN, f"golden_meta_{stem}.json")) as f:
+            meta = json.load(f)["cases"]
+        z = np.load(os.path.join(GOLDEN, f"pyramids_{stem}.npz"))
+        for name, info in meta.items():
+            img = z[f"{name}/image"]
+            levels = [z[f"{name}/L{i}"] for i in range(info["n_levels"])]
+            yield name, img, info, levels
 
 
 def chanfunc_arg_cases():

@@ -17,6 +17,7 @@ WB_DTYPE_U8, WB_DTYPE_F32, WB_DTYPE_RANK8 = 0, 1, 2
 WB_DTYPE_F64, WB_DTYPE_I8, WB_DTYPE_I16, WB_DTYPE_U16, WB_DTYPE_I32, WB_DTYPE_U32 = 3, 4, 5, 6, 7, 8
 WB_ERR_INVALID, WB_ERR_HIP, WB_ERR_UNSUPPORTED = -1, -2, -3
 WB_DET_SHARDS = 64
+WB_DTYPE_I64, WB_DTYPE_U64, WB_DTYPE_BOOL, WB_DTYPE_F16 = 9, 10, 11, 12
 WB_CHN_GRAD_HIST, WB_CHN_GRAD_HIST_4_U1, WB_CHN_GRAD_MAG_U1, WB_CHN_GRAD_MAG = 0, 1, 2, 3
 WB_ABI_VERSION = 5
 
@@ -49,8 +50,8 @@ SYMBOLS = {
     "wb_channels_launch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int,
                                      _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P, C.c_int64,
                                      _P, _P, C.c_int64]),
-    "wb_grad_hist_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_double), _P]),
-    "wb_grad_mag_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, _P, _P]),
+    "wb_grad_hist_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double), _P]),
+    "wb_grad_mag_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_double, C.c_int, _P, _P]),
     "wb_model_create": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "wb_model_destroy": (C.c_int, [_P]),
     "wb_model_info": (C.c_int, [_P, C.POINTER(WbModelInfo)]),

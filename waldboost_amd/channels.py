@@ -42,14 +42,15 @@ def _on_bare_image(image, spec):
     return eng.read_level(0, 0)
 
 
-def _python_scalar_f32(x, what):
-    """float32 value of a scalar that NumPy treats as weak next to a float32 array (Python int / float / bool, or a
-    float32 / float16 / small-integer NumPy scalar): the reference's `array - bias` / `array + eps` then stay float32.
-    A float64 / int64 NumPy scalar would turn the reference's result into float64 -- not provided here."""
+def _scalar_arg(x, what):
+    """(value, wide) of a scalar the reference combines with a float32 array (`array - bias`, `norm + eps`) under NumPy-2
+    promotion: Python int / float / bool and float32 / float16 / small-integer NumPy scalars are weak -- the value is
+    rounded to float32, the arithmetic stays float32 (wide False); a float64 / int64 NumPy scalar makes it float64."""
     if type(x) in (bool, int, float) or np.result_type(np.float32, x) == np.float32:     # (np.float64 subclasses float)
-        return float(np.float32(x))
-    raise NotImplementedError(f"{what}={x!r} ({type(x).__name__}) makes the reference compute in float64; pass a Python "
-                              "scalar or a float32")
+        return float(np.float32(x)), False
+    if np.result_type(np.float32, x) == np.float64 and np.ndim(x) == 0:
+        return float(np.float64(x)), True
+    raise NotImplementedError(f"{what}={x!r} ({type(x).__name__}) has no kernel: pass a real scalar")
 
 
 def grad_hist(image, n_bins=4, full=False, bias=0):
@@ -62,17 +63,17 @@ def grad_hist(image, n_bins=4, full=False, bias=0):
     n_bins = int(n_bins)
     if not 1 <= n_bins <= 32:
         raise NotImplementedError(f"grad_hist: n_bins={n_bins} has no kernel (1..32)")
-    b32 = _python_scalar_f32(bias, "bias")
+    bias_v, wide = _scalar_arg(bias, "bias")
     img = np.ascontiguousarray(image.astype("f"))
     H, W = img.shape
     if H < 1 or W < 1:
-        return np.empty((H, W, n_bins), np.float32)
+        return np.empty((H, W, n_bins), np.float64 if wide else np.float32)
     dev = nat.require_gpu()
     theta = np.linspace(0, 2 * np.pi if full else np.pi, n_bins + 1)          # reference channels.py:43-46
     cs_sn = np.concatenate([np.cos(theta[:-1]), np.sin(theta[:-1])]).astype(np.float64)
     d = torch.from_numpy(img).to(dev)
-    out = torch.empty((H, W, n_bins), dtype=torch.float32, device=dev)
-    nat.check(nat.load().wb_grad_hist_launch(nat.stream_ptr(), nat.ptr(d), H, W, n_bins, int(bool(full)), b32,
+    out = torch.empty((H, W, n_bins), dtype=torch.float64 if wide else torch.float32, device=dev)
+    nat.check(nat.load().wb_grad_hist_launch(nat.stream_ptr(), nat.ptr(d), H, W, n_bins, int(bool(full)), bias_v, int(wide),
                                              cs_sn.ctypes.data_as(C.POINTER(C.c_double)), nat.ptr(out)), "wb_grad_hist_launch")
     return out.cpu().numpy()
 
@@ -99,14 +100,15 @@ def grad_mag(image, norm=5, eps=1e-3):
         taps = np.ascontiguousarray(triangle_kernel(int(norm)), np.float32)
         if taps.size > 127:
             raise NotImplementedError(f"grad_mag: norm={norm} has no kernel (up to 63)")
-        e32 = _python_scalar_f32(eps, "eps")
+        eps_v, wide = _scalar_arg(eps, "eps")
     dev = nat.require_gpu()
     d = torch.from_numpy(img).to(dev)
     out = torch.empty((H, W), dtype=torch.float32, device=dev)
     scratch = torch.empty((2, H, W), dtype=torch.float32, device=dev) if taps is not None else None
     nat.check(nat.load().wb_grad_mag_launch(nat.stream_ptr(), nat.ptr(d), H, W, 0 if taps is None else int(taps.size),
                                             None if taps is None else taps.ctypes.data_as(C.POINTER(C.c_float)),
-                                            0.0 if taps is None else e32, nat.ptr(scratch), nat.ptr(out)), "wb_grad_mag_launch")
+                                            0.0 if taps is None else eps_v, 0 if taps is None else int(wide), nat.ptr(scratch),
+                                            nat.ptr(out)), "wb_grad_mag_launch")
     return out.cpu().numpy()[..., None]
 
 

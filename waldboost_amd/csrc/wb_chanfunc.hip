@@ -15,8 +15,10 @@ struct GhArgs {
     const float *img;
     int H, W, n_bins, full;
     float bias;
+    double bias64;                  // wide: a float64 / int64 NumPy scalar -- |chns| - bias and the rest in float64
+    int wide;
     double cs[WB_GH_MAX_BINS], sn[WB_GH_MAX_BINS];
-    float *out;
+    void *out;
 };
 
 // scipy 'reflect' (d c b a | a b c d | d c b a) for any distance outside [0, n)
@@ -54,13 +56,19 @@ __global__ __launch_bounds__(256) void grad_hist_args_kernel(GhArgs a) {
     float gx, gy;
     gradients_at(a.img, a.H, a.W, y, x, gx, gy);
     const double gxd = (double)gx, gyd = (double)gy;
-    float *o = a.out + i * a.n_bins;
+    float *o = reinterpret_cast<float *>(a.out) + i * a.n_bins;
+    double *o64 = reinterpret_cast<double *>(a.out) + i * a.n_bins;
     for (int k = 0; k < a.n_bins; ++k) {
         const float c = (float)(gxd * a.cs[k] - gyd * a.sn[k]);
-        const float value = fmaxf(fabsf(c) - a.bias, 0.0f);               // np.fmax: a NaN operand loses
         // np.sign: -1 / 0 / +1 (NaN stays NaN)
         const float sg = c > 0.0f ? 1.0f : (c < 0.0f ? -1.0f : (c == c ? 0.0f : c));
-        o[k] = a.full ? sg * value : value;
+        if (a.wide) {
+            const double value = fmax(fabs((double)c) - a.bias64, 0.0);   // float32 array - float64 scalar: float64
+            o64[k] = a.full ? (double)sg * value : value;
+        } else {
+            const float value = fmaxf(fabsf(c) - a.bias, 0.0f);           // np.fmax: a NaN operand loses
+            o[k] = a.full ? sg * value : value;
+        }
     }
 }
 
@@ -82,7 +90,7 @@ struct TriArgs {
 // jj = -size1..-1: tmp += (x[l+jj] + x[l-jj]) * w[c+jj]; one rounding.  divide_by: 0 = store the filtered value,
 // else out = mag / (filtered + eps) in float32 (reference channels.py:35-36).
 __global__ __launch_bounds__(256) void tri_pass_kernel(const float *src, int H, int W, int axis, TriArgs t, const float *mag,
-                                                       float eps, float *dst) {
+                                                       float eps, double eps64, int wide, float *dst) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)H * W) return;
     const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
@@ -94,18 +102,20 @@ __global__ __launch_bounds__(256) void tri_pass_kernel(const float *src, int H, 
     double tmp = at(l) * t.w[size1];
     for (int jj = -size1; jj < 0; ++jj) tmp = tmp + (at(l + jj) + at(l - jj)) * t.w[size1 + jj];
     const float f = (float)tmp;
-    dst[i] = mag ? mag[i] / (f + eps) : f;
+    // (wide: `mag /= norm + eps` with a float64 eps -- the sum and the quotient are float64, stored back as float32)
+    dst[i] = mag ? (wide ? (float)((double)mag[i] / ((double)f + eps64)) : mag[i] / (f + eps)) : f;
 }
 
 }  // namespace
 
-extern "C" int wb_grad_hist_launch(void *stream, const float *img, int H, int W, int n_bins, int full, float bias,
-                                   const double *cs_sn, float *out) {
+extern "C" int wb_grad_hist_launch(void *stream, const float *img, int H, int W, int n_bins, int full, double bias, int wide,
+                                   const double *cs_sn, void *out) {
     WB_REQUIRE(img && cs_sn && out, "wb_grad_hist_launch: null pointer");
     WB_REQUIRE(H >= 1 && W >= 1 && (int64_t)H * W < (1ll << 31) * 256, "wb_grad_hist_launch: bad shape %dx%d", H, W);
     WB_REQUIRE(n_bins >= 1 && n_bins <= WB_GH_MAX_BINS, "wb_grad_hist_launch: n_bins=%d (1..%d)", n_bins, WB_GH_MAX_BINS);
     GhArgs a;
-    a.img = img; a.H = H; a.W = W; a.n_bins = n_bins; a.full = full != 0; a.bias = bias; a.out = out;
+    a.img = img; a.H = H; a.W = W; a.n_bins = n_bins; a.full = full != 0; a.bias = (float)bias; a.bias64 = bias; a.wide = wide != 0;
+    a.out = out;
     for (int k = 0; k < n_bins; ++k) {
         a.cs[k] = cs_sn[k];
         a.sn[k] = cs_sn[n_bins + k];
@@ -115,7 +125,7 @@ extern "C" int wb_grad_hist_launch(void *stream, const float *img, int H, int W,
     return WB_OK;
 }
 
-extern "C" int wb_grad_mag_launch(void *stream, const float *img, int H, int W, int n_taps, const float *taps, float eps,
+extern "C" int wb_grad_mag_launch(void *stream, const float *img, int H, int W, int n_taps, const float *taps, double eps, int wide,
                                   float *scratch, float *out) {
     WB_REQUIRE(img && out, "wb_grad_mag_launch: null pointer");
     WB_REQUIRE(H >= 1 && W >= 1 && (int64_t)H * W < (1ll << 31) * 256, "wb_grad_mag_launch: bad shape %dx%d", H, W);
@@ -130,8 +140,8 @@ extern "C" int wb_grad_mag_launch(void *stream, const float *img, int H, int W, 
         t.n_taps = n_taps;
         for (int k = 0; k < n_taps; ++k) t.w[k] = (double)taps[k];
         float *tmp = scratch + (int64_t)H * W;
-        hipLaunchKernelGGL(tri_pass_kernel, grid, dim3(256), 0, st, (const float *)mag, H, W, 0, t, (const float *)nullptr, 0.0f, tmp);
-        hipLaunchKernelGGL(tri_pass_kernel, grid, dim3(256), 0, st, (const float *)tmp, H, W, 1, t, (const float *)mag, eps, out);
+        hipLaunchKernelGGL(tri_pass_kernel, grid, dim3(256), 0, st, (const float *)mag, H, W, 0, t, (const float *)nullptr, 0.0f, 0.0, 0, tmp);
+        hipLaunchKernelGGL(tri_pass_kernel, grid, dim3(256), 0, st, (const float *)tmp, H, W, 1, t, (const float *)mag, (float)eps, eps, wide, out);
     }
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;

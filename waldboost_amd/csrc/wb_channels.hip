@@ -34,7 +34,7 @@ struct ChanArgs {
     float c2hi, c2lo;    // cos(pi/2) (fp64: 6.1e-17) likewise
     double tri[11];      // grad_mag: triangle_kernel(5) (float32 values, widened)
     float gm_eps;        // grad_mag: float32(1e-3)
-    int src_int;         // float64-held integer image: the resize result is truncated toward zero (.astype(int dtype))
+    int src_int;         // float64-held image dtypes: how the resize result is cast back (WB_CAST_*: .astype(image dtype))
     int dbg;             // diagnostics (WB_CHAN_DBG): 1 = stop after step 1, 2 = after step 2, 4 = skip the stores
     // optional second output of channels_kernel: the pixels as threshold ranks of one model (WB_DTYPE_RANK8)
     uint8_t *rank;       // [u][v][4] bytes per level, same element offsets as chn; nullptr = none
@@ -169,7 +169,12 @@ template <> struct Src<double> {
     static __device__ float finish(double t, double mn, double mx, int src_int) {
         if (mn != mn || mx != mx) return __builtin_nanf("");     // (np.clip with a NaN bound: see Src<float>::finish)
         t = t < mn ? mn : (t > mx ? mx : t);
-        return (float)(src_int ? trunc(t) : t);
+        switch (src_int) {
+            case WB_CAST_TRUNC: t = trunc(t); break;
+            case WB_CAST_BOOL: t = t != 0.0 ? 1.0 : 0.0; break;
+            case WB_CAST_F16: t = wb_round_f16(t); break;
+        }
+        return (float)t;
     }
     static __device__ bool taps_finite(double a, double b, double c) { return fabs(a) < INFINITY && fabs(b) < INFINITY && fabs(c) < INFINITY; }
     static __device__ float hpass(float a, float b, float c) { return Src<float>::hpass(a, b, c); }
@@ -1462,8 +1467,8 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
         return launch_dtype<uint8_t, false>(st, grid, a, shrink, smooth != 0, tile32());
     }
     if (dtype == WB_DTYPE_F32) return launch_dtype<float, false>(st, grid, a, shrink, smooth != 0, tile32());
-    if (dtype == WB_DTYPE_F64 || (dtype >= WB_DTYPE_I8 && dtype <= WB_DTYPE_U32)) {
-        a.src_int = dtype != WB_DTYPE_F64;
+    if (wb_dtype_held_f64(dtype)) {
+        a.src_int = wb_cast_mode(dtype);
         return launch_dtype<double, false>(st, grid, a, shrink, smooth != 0, tile32());
     }
     wb_set_error("wb_channels_launch: unsupported image dtype code %d", dtype);

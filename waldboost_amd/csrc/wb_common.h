@@ -44,6 +44,28 @@ __host__ __device__ inline float wb_key_f32(uint32_t k) {
     return f;
 }
 
+// ---- how a float64-held image dtype is cast back after the resize / pooled in the octaves (WB_DTYPE_F64 .. WB_DTYPE_F16) ----
+#define WB_CAST_NONE 0     // float64
+#define WB_CAST_TRUNC 1    // integers: truncation toward zero
+#define WB_CAST_BOOL 2     // bool: != 0
+#define WB_CAST_F16 3      // float16: round to nearest even
+inline int wb_cast_mode(int dtype) {
+    switch (dtype) {
+        case WB_DTYPE_F64: return WB_CAST_NONE;
+        case WB_DTYPE_BOOL: return WB_CAST_BOOL;
+        case WB_DTYPE_F16: return WB_CAST_F16;
+        default: return WB_CAST_TRUNC;
+    }
+}
+inline bool wb_dtype_held_f64(int dtype) { return dtype == WB_DTYPE_F64 || (dtype >= WB_DTYPE_I8 && dtype <= WB_DTYPE_F16); }
+// a double rounded to binary16 (round to nearest even, one rounding): to float32 toward zero with the sticky bit kept
+// in the last place (round to odd), then the hardware's float32 -> float16 conversion
+__device__ inline double wb_round_f16(double x) {
+    float f = __double2float_rz(x);
+    if ((double)f != x) f = __uint_as_float(__float_as_uint(f) | 1u);     // (inexact; a NaN stays a NaN)
+    return (double)(float)(_Float16)f;
+}
+
 // ---- cascade geometry ----
 #define WB_CASC_TC 64        // windows per tile row = one per lane
 #define WB_CASC_MAX_DEPTH 3

@@ -324,9 +324,15 @@ __global__ __launch_bounds__(256) void pool_f64_kernel(const double *src_base, i
         const double *p0 = src + (int64_t)(2 * r) * sw + 2 * c;
         const double a = p0[0], b = p0[sw], cc = p0[1], d = p0[sw + 1];      // [2r,2c], [2r+1,2c], [2r,2c+1], [2r+1,2c+1]
         double v;
-        if (bits) {
+        if (bits > 0) {
             // each add wraps in the array's dtype; wrapping once at the end is the same residue
             v = trunc(wrap_int(((a + b) + cc) + d, bits, sgn) / 4.0);
+        } else if (bits == -WB_CAST_TRUNC) {
+            v = trunc((((a + b) + cc) + d) / 4.0);          // int64 / uint64 values exact in float64: no rounding, no wrap
+        } else if (bits == -WB_CAST_BOOL) {
+            v = (a != 0.0 || b != 0.0 || cc != 0.0 || d != 0.0) ? 1.0 : 0.0;    // bool + bool is logical or; x / 4 != 0
+        } else if (bits == -WB_CAST_F16) {
+            v = wb_round_f16(wb_round_f16(wb_round_f16(wb_round_f16(a + b) + cc) + d) / 4.0);   // every float16 add rounds
         } else {
             v = (((a + b) + cc) + d) / 4.0;
         }
@@ -348,6 +354,9 @@ int launch_octaves_f64(hipStream_t st, const double *img, int dtype, int batch, 
         case WB_DTYPE_U16: bits = 16; break;
         case WB_DTYPE_I32: bits = 32; sgn = 1; break;
         case WB_DTYPE_U32: bits = 32; break;
+        case WB_DTYPE_I64: case WB_DTYPE_U64: bits = -WB_CAST_TRUNC; break;     // (negative: no wrap, see pool_f64_kernel)
+        case WB_DTYPE_BOOL: bits = -WB_CAST_BOOL; break;
+        case WB_DTYPE_F16: bits = -WB_CAST_F16; break;
     }
     const int64_t n0 = (int64_t)H * W;
     int blocks = (int)((n0 + 255) / 256);
@@ -419,7 +428,7 @@ extern "C" int wb_octaves_launch(void *stream, const void *img, int dtype, int b
         return launch_octaves<uint8_t>(st, (const uint8_t *)img, batch, H, W, img_stride, (uint8_t *)oct, oct_stride, oct_off, n_oct, minmax);
     if (dtype == WB_DTYPE_F32)
         return launch_octaves<float>(st, (const float *)img, batch, H, W, img_stride, (float *)oct, oct_stride, oct_off, n_oct, minmax);
-    if (dtype == WB_DTYPE_F64 || (dtype >= WB_DTYPE_I8 && dtype <= WB_DTYPE_U32))
+    if (wb_dtype_held_f64(dtype))
         return launch_octaves_f64(st, (const double *)img, dtype, batch, H, W, img_stride, (double *)oct, oct_stride, oct_off, n_oct,
                                   reinterpret_cast<unsigned long long *>(minmax));
     wb_set_error("wb_octaves_launch: unsupported image dtype code %d", dtype);

@@ -44,7 +44,11 @@ def _torch_dtype(np_dtype):
 _IMAGE_CODES = {np.dtype(np.uint8): (np.uint8, nat.WB_DTYPE_U8), np.dtype(np.float32): (np.float32, nat.WB_DTYPE_F32),
                 np.dtype(np.float64): (np.float64, nat.WB_DTYPE_F64), np.dtype(np.int8): (np.float64, nat.WB_DTYPE_I8),
                 np.dtype(np.int16): (np.float64, nat.WB_DTYPE_I16), np.dtype(np.uint16): (np.float64, nat.WB_DTYPE_U16),
-                np.dtype(np.int32): (np.float64, nat.WB_DTYPE_I32), np.dtype(np.uint32): (np.float64, nat.WB_DTYPE_U32)}
+                np.dtype(np.int32): (np.float64, nat.WB_DTYPE_I32), np.dtype(np.uint32): (np.float64, nat.WB_DTYPE_U32),
+                # (int64 / uint64: only values exact in float64 -- load_images checks; bool adds are logical ors; every
+                # float16 add rounds to float16)
+                np.dtype(np.int64): (np.float64, nat.WB_DTYPE_I64), np.dtype(np.uint64): (np.float64, nat.WB_DTYPE_U64),
+                np.dtype(np.bool_): (np.float64, nat.WB_DTYPE_BOOL), np.dtype(np.float16): (np.float64, nat.WB_DTYPE_F16)}
 
 
 def image_code(np_dtype):
@@ -53,8 +57,8 @@ def image_code(np_dtype):
         return _IMAGE_CODES[np.dtype(np_dtype)]
     except KeyError:
         raise NotImplementedError(
-            f"image dtype {np.dtype(np_dtype)} has no HIP kernel (uint8, float32, float64, int8, int16, uint16, int32 "
-            "and uint32 are supported)") from None
+            f"image dtype {np.dtype(np_dtype)} has no HIP kernel (uint8, float16 / 32 / 64, bool and the 8 to 64 bit "
+            "integers are supported)") from None
 
 
 def array_dtype(images):
@@ -426,6 +430,10 @@ class PyramidEngine:
             if images.dtype != self.dtype:
                 raise TypeError(f"engine built for {self.dtype} images, got {images.dtype}")
             if images.dtype != self.store_dtype:
+                if images.dtype.itemsize == 8 and images.dtype.kind in "iu" and images.size:
+                    # (64-bit integers are held as float64: exact -- also their 2x2 sums -- below 2^51)
+                    if max(abs(int(images.max())), abs(int(images.min()))) >= 1 << 51:
+                        raise NotImplementedError("64 bit integer images are supported for values below 2**51 (they are held as float64)")
                 images = images.astype(self.store_dtype)           # integer types travel as float64 (exact)
             if images.ndim == 2:
                 images = images[None]
@@ -434,6 +442,9 @@ class PyramidEngine:
             t = None
         else:
             t = images[None] if images.dim() == 2 else images
+            if self.dtype.itemsize == 8 and self.dtype.kind in "iu" and t.numel():
+                if float(t.to(torch.float64).abs().max()) >= float(1 << 51):
+                    raise NotImplementedError("64 bit integer images are supported for values below 2**51 (they are held as float64)")
             if tuple(t.shape) != want:
                 raise ValueError(f"expected images of shape {want}, got {tuple(t.shape)}")
         if t is None:
