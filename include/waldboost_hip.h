@@ -212,6 +212,21 @@ int wb_channels_launch(void *stream, const void *img, int64_t img_stride, const 
                        void *chn, int64_t chn_stride, const WbModel *rank_model, uint8_t *rank,
                        int64_t rank_stride);
 
+/* The pyramid around a channel function this library has no kernel for (channels.py:119,136 calls whatever callable
+ * channel_opts["channels"] holds -- the caller runs it, between these two):
+ *   wb_resize_level_launch  one level's resized image, cast back to the image dtype (channels.py:132): level_host = HOST
+ *                           WbLevel of that level, minmax_host = HOST copy of the level's octave's (min, max) keys as
+ *                           wb_octaves_launch left them (two 32-bit words; two 64-bit words for the float64-held dtypes),
+ *                           img / oct / taps dev as for wb_channels_launch (batch 1); out dev [nh][nw] of uint8 / float32 /
+ *                           float64 (the float64-held dtypes: the cast value, as a double)
+ *   wb_pool_smooth_launch   avg_pool_2 (shrink = 2, channels.py:55-64) and smooth_image_3d (smooth = 1, :78-90) of the
+ *                           callable's result in dev [H][W][C] uint8 or float32 -> out dev [H/shrink][W/shrink][C]; tmp =
+ *                           dev scratch of the pooled size when both steps run */
+int wb_resize_level_launch(void *stream, const void *img, const void *oct, int dtype, const WbLevel *level_host,
+                           const uint32_t *minmax_host, const WbTap *taps, void *out);
+int wb_pool_smooth_launch(void *stream, const void *in, int chn_dtype, int H, int W, int C, int shrink, int smooth, void *tmp,
+                          void *out);
+
 /* The channel functions called directly on one float32 image (the caller's image.astype("f")) WITH ARGUMENTS
  * (reference channels.py:40-52 grad_hist(image, n_bins, full, bias) and :30-37 grad_mag(image, norm, eps); with
  * their default arguments, and inside channel_pyramid, they run in wb_channels_launch).

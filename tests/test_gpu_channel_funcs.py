@@ -293,3 +293,56 @@ def test_channel_function_arguments_that_change_the_arithmetic_dtype():
     assert wb.channels.grad_hist(img, n_bins=3, bias=np.float32(1.0)).dtype == np.float32
     with pytest.raises(NotImplementedError):
         wb.channels.grad_hist(img, bias=np.complex64(1.0))
+
+
+# ------------------------------------------------------------------------------ a channel function without a kernel
+def _two_channels(im):
+    """A caller's own channel function (reference channels.py:119,136 calls whatever channel_opts["channels"] holds)."""
+    f = im.astype("f")
+    return np.stack([f * np.float32(0.5), np.sqrt(np.abs(f) + np.float32(1.0))], -1)
+
+
+def _inverted_u8(im):
+    return (255 - im.astype(np.uint8))[..., None]
+
+
+@pytest.mark.parametrize("func,dtype,shrink,smooth", [(_two_channels, np.uint8, 2, 1), (_two_channels, np.float32, 1, 1),
+                                                      (_two_channels, np.int16, 2, 0), (_inverted_u8, np.uint8, 2, 1),
+                                                      (_inverted_u8, np.uint8, 1, 0)])
+def test_pyramid_around_a_callable_without_a_kernel_vs_oracle(func, dtype, shrink, smooth):
+    """The GPU computes the octaves, every level's resize and cast back, avg_pool_2 and smooth_image_3d; the caller's
+    function runs on the host array it is handed -- every level bit-exact against the oracle running the same function."""
+    import waldboost_amd as wb
+    img = synth_image(150, 201, 9)
+    img = (img.astype(np.int32) * 100 - 9000).astype(dtype) if dtype == np.int16 else img.astype(dtype)
+    opts = dict(shrink=shrink, n_per_oct=4, smooth=smooth, channels=func)
+    got = list(wb.channels.channel_pyramid(img, opts))
+    ref = list(orc.channel_pyramid(img, opts))
+    assert len(got) == len(ref) > 4
+    for (c, s), (rc, rs) in zip(got, ref):
+        assert s == rs and c.dtype == rc.dtype and c.shape == rc.shape
+        assert np.array_equal(c.view(np.uint8), np.ascontiguousarray(rc).view(np.uint8))
+    with pytest.raises(NotImplementedError):
+        list(wb.channels.channel_pyramid(img, dict(opts, channels=lambda im: im.astype(np.float64)[..., None])))
+
+
+def test_model_detect_with_a_callable_without_a_kernel_vs_oracle():
+    import waldboost_amd as wb
+    from waldboost_amd.synth import random_tree_arrays
+    from util import oracle_detect
+    rng = np.random.default_rng(4)
+    shape = (10, 12, 2)
+    M = wb.Model(shape, dict(shrink=2, n_per_oct=4, smooth=1, channels=_two_channels))
+    acc = 0.0
+    for t in range(12):
+        f, th, l, r, p = random_tree_arrays(rng, shape, 2, 4.0, 60.0)
+        acc -= 0.3
+        M.append(wb.DTree(f, th, l, r, p), float(np.float32(acc)))
+    img = synth_image(160, 220, 3)
+    trees = [orc.make_tree(w.feature, w.threshold, w.left, w.right, w.prediction) for w in M.classifier]
+    ref = orc.detect(shape, dict(M.channel_opts), trees, list(M.theta), img)
+    res = M.detect_raw(img)
+    assert ref["scores"].size > 0 and np.array_equal(res["alive"], ref["alive"])
+    assert np.array_equal(res["level"], ref["level"]) and np.array_equal(res["r"], ref["r"]) and np.array_equal(res["c"], ref["c"])
+    assert np.array_equal(res["scores"].view(np.uint32), ref["scores"].view(np.uint32)) and np.array_equal(res["boxes"], ref["boxes"])
+    assert len(M.detect(img)) == ref["scores"].size and M.n_loc == 2 * ref["n_loc"]

@@ -50,6 +50,8 @@ SYMBOLS = {
     "wb_channels_launch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int,
                                      _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P, C.c_int64,
                                      _P, _P, C.c_int64]),
+    "wb_resize_level_launch": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, _P]),
+    "wb_pool_smooth_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "wb_grad_hist_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double), _P]),
     "wb_grad_mag_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_double, C.c_int, _P, _P]),
     "wb_model_create": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),

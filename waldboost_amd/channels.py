@@ -166,15 +166,17 @@ def is_grad_hist(func):
     return channel_spec(func) is SPECS["grad_hist"]
 
 
-def read_opts(channel_opts):
-    """(shrink, n_per_oct, smooth, spec) of a channel_opts dict (reference channels.py:116-120)."""
+def read_opts(channel_opts, allow_callable=False):
+    """(shrink, n_per_oct, smooth, spec) of a channel_opts dict (reference channels.py:116-120).  allow_callable: a
+    channel function without a kernel gives spec None (the caller then runs the function itself between the GPU steps)
+    instead of NotImplementedError."""
     shrink = channel_opts["shrink"]
     n_per_oct = channel_opts["n_per_oct"]
     smooth = channel_opts["smooth"]
     channels = channel_opts["channels"]
     assert shrink in [1, 2, 4], "Shrink factor must be integer 1 <= shrink <= 2 (4: extension of this build)"
     spec = channel_spec(channels)
-    if spec is None:
+    if spec is None and not (allow_callable and callable(channels)):
         raise NotImplementedError(f"channel function {channels!r} has no HIP kernel (known: {sorted(SPECS)})")
     if smooth not in (0, 1):
         smooth = 0          # the reference smooths only when smooth == 1 (channels.py:141)
@@ -188,7 +190,10 @@ def channel_pyramid(image, channel_opts):
     caller that stops early pays for the levels it consumed.  (Model.detect does not go through this generator:
     it computes the whole pyramid in one launch and scans it on the GPU.)"""
     _validate_image(image)
-    shrink, n_per_oct, smooth, spec = read_opts(channel_opts)
+    shrink, n_per_oct, smooth, spec = read_opts(channel_opts, allow_callable=True)
+    if spec is None:
+        yield from _callable_pyramid(image, shrink, n_per_oct, smooth, channel_opts["channels"])
+        return
     if spec.dtype == np.uint8:
         _require_u8(image, spec.key)
     H, W = image.shape
@@ -206,3 +211,29 @@ def channel_pyramid(image, channel_opts):
             mine = eng.epoch
         eng.launch_level(l)
         yield np.atleast_3d(eng.read_level(0, l)), eng.plan.scales[l]
+
+
+def _callable_pyramid(image, shrink, n_per_oct, smooth, func):
+    """channel_pyramid around a channel function this build has no kernel for (reference channels.py:119,136 calls
+    whatever callable channel_opts["channels"] holds): octaves, each level's resize and cast (wb_resize_level_launch),
+    avg_pool_2 and smooth_image_3d of the function's result (wb_pool_smooth_launch) run on the GPU; the caller's function
+    runs where it runs -- it is handed the resized image as a host ndarray of the image's dtype and returns [H,W(,C)]
+    uint8 or float32."""
+    if shrink not in (1, 2):
+        raise NotImplementedError("shrink must be 1 or 2 around a channel function without a kernel")
+    H, W = image.shape
+    eng = _engine.get_engine(H, W, image.dtype, shrink, n_per_oct, smooth, 1, channels=SPECS["grad_hist"])   # octaves, level table, taps
+    mine = None
+    for l in range(eng.plan.n_levels):
+        if eng.epoch != mine:
+            eng.load_images(image)
+            eng.reset_step(None, octaves=True)
+            eng.launch_octaves()
+            mine = eng.epoch
+        im = eng.resize_level(l)
+        chns = np.asarray(func(im))
+        if chns.ndim not in (2, 3) or chns.shape[:2] != im.shape:
+            raise ValueError(f"the channel function returned shape {chns.shape} for a {im.shape} image")
+        if chns.dtype not in (np.dtype(np.uint8), np.dtype(np.float32)):
+            raise NotImplementedError(f"channel arrays of dtype {chns.dtype} have no avg_pool_2 / smooth kernel (uint8 and float32 do)")
+        yield np.atleast_3d(eng.pool_smooth(chns if chns.ndim == 3 else chns[..., None])), eng.plan.scales[l]

@@ -1364,6 +1364,158 @@ void set_constants(ChanArgs &a, const double *cs_sn) {
 
 }  // namespace
 
+// -------------------------------------------------------------------------------------------
+// The pyramid around a channel function this build has no kernel for (reference channels.py:119,136 calls whatever
+// callable channel_opts["channels"] holds): the steps on either side of the caller's function as plain kernels --
+//   resize_level_kernel   one level's resized image (channels.py:132), cast back to the image dtype
+//   pool2_kernel          avg_pool_2 of an [H][W][C] array (channels.py:55-64): uint8 adds wrap, float32 ((a+b)+c)+d
+//   smooth_kernel         smooth_image_3d (channels.py:78-90): nine-term sum in source order (float32 channels: fp64;
+//                         uint8 channels: integers), / 16, cast back; 1-pixel border 0
+// One thread per output element, through global memory: correct rather than tuned (the callable between them runs on
+// the host anyway).
+namespace {
+
+template <typename T, typename O>
+__global__ __launch_bounds__(256) void resize_level_kernel(const T *src, int src_w, int nh, int nw, const WbTap *rtap, const WbTap *ctap,
+                                                           double mn, double mx, int cast_mode, O *out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)nh * nw) return;
+    const int y = (int)(i / nw), x = (int)(i - (int64_t)y * nw);
+    const WbTap tr = rtap[y], tc = ctap[x];
+    const T *r0 = src + (int64_t)tr.i0 * src_w, *r1 = src + (int64_t)tr.i1 * src_w;
+    const double t = resample_f64((double)r0[tc.i0], (double)r0[tc.i1], (double)r1[tc.i0], (double)r1[tc.i1], tr, tc);
+    if constexpr (sizeof(T) == 8) {
+        // float64-held dtypes: the value after the clip and the cast back, still as a double (Src<double>::finish
+        // rounds to float32 for the channel kernels; here the caller gets the image dtype's own value)
+        double v = t;
+        if (mn != mn || mx != mx) v = __builtin_nan("");
+        else v = v < mn ? mn : (v > mx ? mx : v);
+        switch (cast_mode) {
+            case WB_CAST_TRUNC: v = trunc(v); break;
+            case WB_CAST_BOOL: v = v != 0.0 ? 1.0 : 0.0; break;
+            case WB_CAST_F16: v = wb_round_f16(v); break;
+        }
+        out[i] = (O)v;
+    } else {
+        out[i] = (O)Src<T>::finish(t, mn, mx, cast_mode);
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void pool2_kernel(const E *in, int H, int W, int C, E *out) {
+    const int oh = H >> 1, ow = W >> 1;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)oh * ow * C) return;
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int y = (int)(p / ow), x = (int)(p - (int64_t)y * ow);
+    auto at = [&](int dy, int dx) { return in[((int64_t)(2 * y + dy) * W + (2 * x + dx)) * C + c]; };
+    if constexpr (sizeof(E) == 1)
+        out[i] = (E)((((uint32_t)at(0, 0) + at(1, 0) + at(0, 1) + at(1, 1)) & 255u) >> 2);
+    else
+        out[i] = (((at(0, 0) + at(1, 0)) + at(0, 1)) + at(1, 1)) * 0.25f;
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void smooth_kernel(const E *in, int H, int W, int C, E *out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)H * W * C) return;
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
+    if (y == 0 || x == 0 || y == H - 1 || x == W - 1) {
+        out[i] = (E)0;
+        return;
+    }
+    auto at = [&](int dy, int dx) { return in[((int64_t)(y + dy) * W + (x + dx)) * C + c]; };
+    if constexpr (sizeof(E) == 1) {
+        const int s = at(-1, -1) + 2 * at(-1, 0) + at(-1, 1) + 2 * at(0, -1) + 4 * at(0, 0) + 2 * at(0, 1) + at(1, -1) + 2 * at(1, 0) + at(1, 1);
+        out[i] = (E)(s >> 4);
+    } else {
+        out[i] = smooth9(at(-1, -1), at(-1, 0), at(-1, 1), at(0, -1), at(0, 0), at(0, 1), at(1, -1), at(1, 0), at(1, 1));
+    }
+}
+
+}  // namespace
+
+extern "C" int wb_resize_level_launch(void *stream, const void *img, const void *oct, int dtype, const WbLevel *level_host,
+                                      const uint32_t *minmax_host, const WbTap *taps, void *out) {
+    WB_REQUIRE(img && level_host && minmax_host && taps && out, "wb_resize_level_launch: null pointer");
+    const WbLevel &L = *level_host;
+    const dim3 grid((unsigned)(((int64_t)L.nh * L.nw + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    const WbTap *rtap = taps + L.tap_off, *ctap = rtap + L.nh;
+    double mn, mx;
+    if (dtype == WB_DTYPE_U8) {
+        mn = (double)(~minmax_host[0]);
+        mx = (double)minmax_host[1];
+        const uint8_t *src = L.oct == 0 ? (const uint8_t *)img : (const uint8_t *)oct + L.src_off;
+        hipLaunchKernelGGL((resize_level_kernel<uint8_t, uint8_t>), grid, dim3(256), 0, st, src, L.src_w, L.nh, L.nw, rtap, ctap, mn, mx, 0, (uint8_t *)out);
+    } else if (dtype == WB_DTYPE_F32) {
+        mn = (double)wb_key_f32(~minmax_host[0]);
+        mx = (double)wb_key_f32(minmax_host[1]);
+        const float *src = L.oct == 0 ? (const float *)img : (const float *)oct + L.src_off;
+        hipLaunchKernelGGL((resize_level_kernel<float, float>), grid, dim3(256), 0, st, src, L.src_w, L.nh, L.nw, rtap, ctap, mn, mx, 0, (float *)out);
+    } else if (wb_dtype_held_f64(dtype)) {
+        const unsigned long long *mm = reinterpret_cast<const unsigned long long *>(minmax_host);
+        auto dec = [](unsigned long long k) {
+            const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+            double d;
+            __builtin_memcpy(&d, &b, 8);
+            return d;
+        };
+        mn = dec(~mm[0]);
+        mx = dec(mm[1]);
+        const double *src = L.oct == 0 ? (const double *)img : (const double *)oct + L.src_off;
+        hipLaunchKernelGGL((resize_level_kernel<double, double>), grid, dim3(256), 0, st, src, L.src_w, L.nh, L.nw, rtap, ctap, mn, mx,
+                           wb_cast_mode(dtype), (double *)out);
+    } else {
+        wb_set_error("wb_resize_level_launch: unsupported image dtype code %d", dtype);
+        return WB_ERR_UNSUPPORTED;
+    }
+    WB_HIP_CHECK(hipGetLastError());
+    return WB_OK;
+}
+
+extern "C" int wb_pool_smooth_launch(void *stream, const void *in, int chn_dtype, int H, int W, int C, int shrink, int smooth,
+                                     void *tmp, void *out) {
+    WB_REQUIRE(in && out && H >= 1 && W >= 1 && C >= 1, "wb_pool_smooth_launch: bad argument");
+    WB_REQUIRE(chn_dtype == WB_DTYPE_U8 || chn_dtype == WB_DTYPE_F32, "wb_pool_smooth_launch: channel dtype %d (uint8 or float32)", chn_dtype);
+    WB_REQUIRE(shrink == 1 || shrink == 2, "wb_pool_smooth_launch: shrink %d (1 or 2)", shrink);
+    WB_REQUIRE(!(shrink == 2 && smooth) || tmp, "wb_pool_smooth_launch: pooling and smoothing need the tmp buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const void *cur = in;
+    int h = H, w = W;
+    if (shrink == 2) {
+        void *dst = smooth ? tmp : out;
+        const int64_t n = (int64_t)(H >> 1) * (W >> 1) * C;
+        if (n > 0) {
+            const dim3 grid((unsigned)((n + 255) / 256));
+            if (chn_dtype == WB_DTYPE_U8)
+                hipLaunchKernelGGL((pool2_kernel<uint8_t>), grid, dim3(256), 0, st, (const uint8_t *)cur, H, W, C, (uint8_t *)dst);
+            else
+                hipLaunchKernelGGL((pool2_kernel<float>), grid, dim3(256), 0, st, (const float *)cur, H, W, C, (float *)dst);
+        }
+        cur = dst;
+        h = H >> 1;
+        w = W >> 1;
+    }
+    if (smooth) {
+        const int64_t n = (int64_t)h * w * C;
+        if (n > 0) {
+            const dim3 grid((unsigned)((n + 255) / 256));
+            if (chn_dtype == WB_DTYPE_U8)
+                hipLaunchKernelGGL((smooth_kernel<uint8_t>), grid, dim3(256), 0, st, (const uint8_t *)cur, h, w, C, (uint8_t *)out);
+            else
+                hipLaunchKernelGGL((smooth_kernel<float>), grid, dim3(256), 0, st, (const float *)cur, h, w, C, (float *)out);
+        }
+    } else if (shrink != 2) {
+        WB_HIP_CHECK(hipMemcpyAsync(out, in, (size_t)H * W * C * (chn_dtype == WB_DTYPE_U8 ? 1 : 4), hipMemcpyDeviceToDevice, st));
+    }
+    WB_HIP_CHECK(hipGetLastError());
+    return WB_OK;
+}
+
 extern "C" int wb_channels_tile(int channel_func, int shrink, int *tile_u, int *tile_v) {
     WB_REQUIRE(tile_u && tile_v, "wb_channels_tile: null pointer");
     if (shrink == 1 || shrink == 2) {

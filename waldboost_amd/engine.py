@@ -363,6 +363,7 @@ class PyramidEngine:
         self.epoch = 0
         self.det_capacity = int(det_capacity)
         self._h_packed = self._h_alive = self._fetch_ev = None
+        self._mm_host = None
         self._final = self._h_final = self._h_final_views = self._inv_scales_d = self._final_dims = None
         self._alloc_det()
         if exact_single:
@@ -513,6 +514,40 @@ class PyramidEngine:
                                               nat.ptr(self.chn), self.chn_stride, None, None, 0),
                   "wb_channels_launch")
 
+
+    # ------------------------------------------------------------------ around a caller's channel function
+    def resize_level(self, l):
+        """Level l's resized image of resident image 0, cast back to the image dtype, as a host ndarray [nh, nw]
+        (reference channels.py:132) -- after launch_octaves."""
+        import torch
+        rec = np.ascontiguousarray(self.level_np[l:l + 1])
+        lv = rec[0]
+        nh, nw = int(lv["nh"]), int(lv["nw"])
+        if self._mm_host is None or self._mm_host[0] != self.epoch:
+            self._mm_host = (self.epoch, self.minmax[0].cpu().numpy().copy())       # (one read-back per image)
+        mm = np.ascontiguousarray(self._mm_host[1][int(lv["oct"])])
+        out = torch.empty((nh, nw), dtype=self.tdtype, device=self.dev)
+        nat.check(self.lib.wb_resize_level_launch(nat.stream_ptr(), nat.ptr(self.img), nat.ptr(self.oct), self.wb_dtype,
+                                                  rec.ctypes.data_as(C.c_void_p),
+                                                  mm.ctypes.data_as(C.c_void_p), nat.ptr(self.taps), nat.ptr(out)),
+                  "wb_resize_level_launch")
+        return out.cpu().numpy().astype(self.dtype, copy=False)
+
+    def pool_smooth(self, chns):
+        """avg_pool_2 (shrink 2) and smooth_image_3d (smooth 1) of a host array [H, W, C] uint8 / float32 -> host array
+        (reference channels.py:138-142)."""
+        import torch
+        p = self.plan
+        H, W, Cn = chns.shape
+        code = nat.WB_DTYPE_U8 if chns.dtype == np.uint8 else nat.WB_DTYPE_F32
+        d = torch.from_numpy(np.ascontiguousarray(chns)).to(self.dev)
+        oh, ow = (H // 2, W // 2) if p.shrink == 2 else (H, W)
+        out = torch.empty((oh, ow, Cn), dtype=d.dtype, device=self.dev)
+        tmp = torch.empty_like(out) if (p.shrink == 2 and p.smooth) else None
+        if H and W and Cn:
+            nat.check(self.lib.wb_pool_smooth_launch(nat.stream_ptr(), nat.ptr(d), code, H, W, Cn, p.shrink, p.smooth,
+                                                     nat.ptr(tmp), nat.ptr(out)), "wb_pool_smooth_launch")
+        return out.cpu().numpy()
 
     def _casc_state(self, dm):
         import torch

@@ -156,7 +156,9 @@ class Model:
         """detect() with everything the parity tests compare: boxes, scores, (level, r, c),
         alive[level, stage]; updates n_loc / n_weak.  (_full=False: boxes and scores only -- what detect() returns.)"""
         _channels._validate_image(image)
-        shrink, n_per_oct, smooth, spec = _channels.read_opts(self.channel_opts)
+        shrink, n_per_oct, smooth, spec = _channels.read_opts(self.channel_opts, allow_callable=True)
+        if spec is None:
+            return self._detect_raw_levelwise(image)
         m, n, Cc = self.shape
         assert Cc == spec.n_channels, f"Invalid number of channels. Expected {Cc} given {spec.n_channels}."
         H, W = image.shape
@@ -172,6 +174,22 @@ class Model:
         # + boxes and sort keys + the read-back: one hipGraph replay from the second call on
         fin = eng.detect_run(dm)
         return self._collect(eng, dm, eng._casc_state(dm), _full, fin)
+
+    def _detect_raw_levelwise(self, image):
+        """detect_raw for a channel function without a kernel: the reference's own loop (model.py:171-177) -- one level at
+        a time from the generator (the caller's function runs between the GPU steps), each scanned on the GPU."""
+        T = len(self)
+        parts, alive, scales = [], [], []
+        for lv, (chns, scale) in enumerate(self.channels(image)):
+            rs, cs, hs, al = self.predict_on_image_stats(chns)
+            alive.append(al)
+            scales.append(scale)
+            if rs.size:
+                parts.append((np.full(rs.size, lv, np.int32), rs, cs, hs, self.get_boxes(rs, cs, scale).get()))
+        cat = lambda k, dt: np.concatenate([p[k] for p in parts]).astype(dt, copy=False) if parts else np.empty(0, dt)
+        return dict(boxes=np.concatenate([p[4] for p in parts]) if parts else np.empty((0, 4), "f"), scores=cat(3, np.float32),
+                    level=cat(0, np.int32), r=cat(1, np.int64), c=cat(2, np.int64),
+                    alive=np.stack(alive) if alive else np.zeros((0, T), np.int64), scales=scales)
 
     def scan_engine(self, eng, view=None):
         """Run this cascade over the channel pyramid already resident in `eng` (channels computed
