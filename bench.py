@@ -247,7 +247,10 @@ def main():
     jit = False
     if os.environ.get("WB_CASC_JIT", "1") != "0" and not args.no_jit:
         t_jit = time.perf_counter()
-        jit = bool(dm.specialize())
+        try:
+            jit = bool(dm.specialize())
+        except Exception as exc:                              # (a compiler failure leaves the generic kernel: say so, go on)
+            print(f"bench: model specialisation failed, staying on the generic cascade kernel: {exc}", file=sys.stderr)
         t_jit = time.perf_counter() - t_jit
     B, P = args.batch, max(1, args.pool)
     engines = []

@@ -406,7 +406,7 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
     // wave must not leave run_segments for the tail before that stage (an override below 16 would skip stages 8..15)
     a.spar[0] = a.spar[0] < 16 ? 16 : a.spar[0];
     a.spar[2] = a.spar[2] < 16 ? 16 : a.spar[2];
-    static const int spar_wg = getenv("WB_CASC_SPAR_WG") ? atoi(getenv("WB_CASC_SPAR_WG")) : 64;
+    static const int spar_wg = getenv("WB_CASC_SPAR_WG") ? atoi(getenv("WB_CASC_SPAR_WG")) : 32;
     a.spar_wg = spar_wg;
     dim3 grid((unsigned)n_tiles, (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;

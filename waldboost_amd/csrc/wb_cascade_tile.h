@@ -63,13 +63,16 @@ __host__ __device__ constexpr size_t wb_lds_tile_bytes(bool u8, int C, int rows,
 __host__ __device__ constexpr size_t wb_lds_stab_off(bool u8, int C, int rows, int pitch, int TR, int T) {
     return (wb_lds_tile_bytes(u8, C, rows, pitch) + (size_t)TR * 64 * 8 + (size_t)T * 4 + 15) & ~(size_t)15;
 }
-#define WB_LDS_CTL_BYTES 128
+#define WB_LDS_CTL_BYTES 256
 // experiment switches (A/B builds; the defaults are what measured best)
 #ifndef WB_TAIL_W
 #define WB_TAIL_W 2          // windows the stage-parallel tail walks side by side
 #endif
 #ifndef WB_TAIL_ALL
 #define WB_TAIL_ALL 1        // tail: gather every node's feature up front (eval_all)
+#endif
+#ifndef WB_TAIL_PRIO
+#define WB_TAIL_PRIO 3       // s_setprio of a wave inside the stage-parallel tail (0 = off)
 #endif
 #ifndef WB_SEG_PREFETCH
 #define WB_SEG_PREFETCH 1    // BAKED segments: next group's gathers before this group's rejection tests
@@ -285,7 +288,7 @@ template <int B, int E, int S, class F> __device__ __forceinline__ void wb_stati
 template <int D, int RPW, int WAVES, bool U8, bool BAKED>
 __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32_t *__restrict__ stages) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    static_assert(2 * WAVES * 4 <= WB_LDS_CTL_BYTES, "control words");
+    static_assert((2 * WAVES + 1) * 4 <= WB_LDS_CTL_BYTES, "control words");
     constexpr int NT = WAVES * 64;
     constexpr int TR = RPW * WAVES;
     constexpr int SD = WB_STAGE_DWORDS(D);
@@ -321,13 +324,19 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     // control words behind the mirror: the per-wave counts exchanged at stage 8 and (their own words) at stage 16
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + stab_off + (size_t)(BAKED ? WB_JIT_T : a.lds_stages) * SD * 4);
     uint32_t *wcnt2 = wcnt + WAVES;
+    uint32_t *ticket = wcnt2 + WAVES;           // next unclaimed entry of the workgroup's survivor list (the stage-parallel tail)
+    if (tid == 0) *ticket = 0u;                 // (visible behind the tile load's barrier)
     if constexpr (BAKED) {
         // the specialised stages address LDS by number: the dynamic region must start at LDS address 0
         if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
     }
     WB_STAMP(0);
     for (int t = tid; t < T; t += NT) hist[t] = 0;
-    for (int i = tid; i < a.lds_stages * (SD / 4); i += NT) stab[i] = reinterpret_cast<const int4 *>(stages)[i];
+    // the stage mirror: its first NT vectors are REQUESTED here and stored behind the tile (as a loop of its own in front
+    // of the tile loads it put one more memory round trip on every workgroup's way to the first barrier)
+    const int n_stab = (BAKED ? WB_JIT_T : a.lds_stages) * (SD / 4);
+    int4 stab_mine = make_int4(0, 0, 0, 0);
+    if (tid < n_stab) stab_mine = reinterpret_cast<const int4 *>(stages)[tid];
 
     // ---- stage the channel block into LDS (planar [C][rows][pitch])
     const float *chn = reinterpret_cast<const float *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
@@ -426,6 +435,8 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
             tile[(ch * rows + row) * pitch + col] = v;
         }
     }
+    if (tid < n_stab) stab[tid] = stab_mine;
+    for (int i = tid + NT; i < n_stab; i += NT) stab[i] = reinterpret_cast<const int4 *>(stages)[i];
     __syncthreads();
     WB_STAMP(1);
     if (a.dbg & 2) return;
@@ -560,8 +571,9 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
         }
     }
     int n_q = my_cnt;
-    int qs = 1;                                                   // stride of this wave's queue entries
     bool scatter = false;
+    const uint2 *dyn_list = nullptr;                              // scatter: the workgroup's shared survivor list ...
+    int dyn_total = 0;                                            // ... and its length
     if (T > S0) {
         __syncthreads();                                          // pooled entries visible; wcnt free again
         if (pooled) {
@@ -572,9 +584,9 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
             // wave-synchronous segments.
             scatter = total <= (uint32_t)a.spar_wg;
             if (scatter) {
-                queue = wgq + wave;
-                qs = WAVES;
-                n_q = (int)total > wave ? ((int)total - wave + WAVES - 1) / WAVES : 0;
+                dyn_list = wgq;                                       // (claimed entry by entry in the tail below)
+                dyn_total = (int)total;
+                n_q = 0;
             } else {
                 queue = wgq + 64 * wave;
                 int left = (int)total - 64 * wave;
@@ -673,7 +685,10 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
                                 // (value and lane index are both scalars; two scalar operands exceed the constant-bus limit, so
                                 // the index travels in m0) instead of a move, a compare and a select
                                 const int cnt = __popcll(am);
-                                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(ent_c) : "s"(cnt), "s"(t + g - t_begin) : "m0");
+                                if constexpr (BAKED)        // (a specialised build only lands here for a segment off its list: plain code)
+                                    ent_c = lane == t + g - t_begin ? (uint32_t)cnt : ent_c;
+                                else
+                                    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(ent_c) : "s"(cnt), "s"(t + g - t_begin) : "m0");
                                 h = h + p[g];                        // (a dead window's sum is never read again)
                                 am &= __ballot(h >= st[g].theta) | (never_rejects<BAKED>(st[g].theta) ? ~0ull : 0ull);
                             }
@@ -731,9 +746,9 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
                 for (int i = lane; i < n_q; i += 64) list2[before2 + i] = queue[i];
                 __syncthreads();
                 scatter = true;
-                queue = list2 + wave;
-                qs = WAVES;
-                n_q = (int)total2 > wave ? ((int)total2 - wave + WAVES - 1) / WAVES : 0;
+                dyn_list = list2;
+                dyn_total = (int)total2;
+                n_q = 0;
                 t_begin = S1;
             }
         }
@@ -742,116 +757,194 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     WB_STAMP(4);
     if (a.dbg & 16) return;
 
-    // ---- stage-parallel tail: one window at a time, lane i evaluates stage rs+i
-    for (int rs = t_begin; rs < T && n_q > 0; rs += 64) {
+    // ---- stage-parallel tail: lane i evaluates stage rs + i of a window (two windows side by side)
+    const uint32_t shard = blockIdx.x % WB_DET_SHARDS;
+    // this lane's record for stage rs + lane (the LDS mirror, or HBM when the table is too large for it)
+    auto lane_stage = [&](int rs) {
+        Stage<D> st;
         const int t = rs + lane;
-        const int nvalid = T - rs < 64 ? T - rs : 64;
-        Stage<D> st;                                             // this lane's own stage
-        {
-            const int tt = t < T ? t : T - 1;
-            int32_t rec[SD];
-            if (a.lds_stages) {
+        const int tt = t < T ? t : T - 1;
+        int32_t rec[SD];
+        if (BAKED || a.lds_stages) {
 #pragma unroll
-                for (int q = 0; q < SD / 4; ++q) {
-                    int4 v = stab[tt * (SD / 4) + q];
-                    rec[4 * q] = v.x; rec[4 * q + 1] = v.y; rec[4 * q + 2] = v.z; rec[4 * q + 3] = v.w;
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < SD / 4; ++q) {
-                    int4 v = reinterpret_cast<const int4 *>(stages)[(size_t)tt * (SD / 4) + q];
-                    rec[4 * q] = v.x; rec[4 * q + 1] = v.y; rec[4 * q + 2] = v.z; rec[4 * q + 3] = v.w;
-                }
+            for (int q = 0; q < SD / 4; ++q) {
+                int4 v = stab[tt * (SD / 4) + q];
+                rec[4 * q] = v.x; rec[4 * q + 1] = v.y; rec[4 * q + 2] = v.z; rec[4 * q + 3] = v.w;
             }
-            st.load(rec);
+        } else {
+#pragma unroll
+            for (int q = 0; q < SD / 4; ++q) {
+                int4 v = reinterpret_cast<const int4 *>(stages)[(size_t)tt * (SD / 4) + q];
+                rec[4 * q] = v.x; rec[4 * q + 1] = v.y; rec[4 * q + 2] = v.z; rec[4 * q + 3] = v.w;
+            }
         }
-        int n_out = 0;
-        uint32_t entered_t = 0;                                  // windows that entered stage rs + lane in this pass
-        // W windows at a time (W = 2 while the queue holds a pair): a window's chain -- gathers, leaf select, the DPP
-        // ripple below -- is all latency, and two independent chains interleave in the same issue slots
-        auto windows = [&](auto w_tag, int i) {
-            constexpr int W = decltype(w_tag)::value;
-            int pos[W];
-            float pk[W], hk[W];
+        st.load(rec);
+        return st;
+    };
+    // W windows (origins pos[], scores h[] on entering stage rs) through the stages rs .. rs + nvalid - 1, one stage per
+    // lane: rej[w] = a stage rejected it; else h[w] = its score behind the last of them.  entered += the number of
+    // these windows that entered stage rs + lane.  A window's chain -- gathers, leaf select, the ripple -- is all
+    // latency: two independent chains interleave in the same issue slots.
+    auto pass = [&](auto w_tag, const Stage<D> &st, int nvalid, const int *pos, float *h, bool *rej, uint32_t &entered) {
+        constexpr int W = decltype(w_tag)::value;
+        float pk[W], hk[W];
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const uint2 e = queue[(i + w) * qs];                 // same entry in every lane
-                pos[w] = __builtin_amdgcn_readfirstlane((int)e.x);
-                const int wbase = ((pos[w] >> 6) * pitch + (pos[w] & 63)) * px_stride;
-                const float p = WB_TAIL_ALL ? st.template eval_all<U8>(tile, wbase) : st.template eval<U8>(tile, wbase);
-                // Replay in stage order: lane k accumulates p_0 .. p_k one after the other -- the same
-                // additions in the same order as the reference's running `hs +=` -- so it ends up
-                // with the score the rejection test of stage rs+k sees.
-                // (ripple through the wave with DPP wave_shr:1 -- lane k takes lane k-1's running sum
-                // and adds its own p; after step j lanes 0..j are final and later steps recompute the
-                // same value, so 63 steps settle every lane)
-                // Lane 0 folds the incoming score into its addend (0 + x == x exactly), so the shifted-in
-                // value of the out-of-range lane can be the DPP zero (bound_ctrl) and each step is ONE
-                // v_add_f32 with a wave_shr:1 source.
-                const float h_in = __uint_as_float(e.y);
-                pk[w] = lane == 0 ? h_in + p : p;
-                hk[w] = pk[w];
-            }
-            // Most windows are rejected within a few stages, so the ripple runs in blocks of 8 steps and stops
-            // at the first block whose settled lanes hold a rejection: the lowest such lane is the first
-            // rejecting stage (every earlier stage is settled and passed).  (A window that is done keeps rippling
-            // beside its partner: its settled lanes recompute the same sums, its verdict is frozen.)
-            unsigned long long rmask[W];
-            bool done[W];
+        for (int w = 0; w < W; ++w) {
+            const int wbase = ((pos[w] >> 6) * pitch + (pos[w] & 63)) * px_stride;
+            const float p = WB_TAIL_ALL ? st.template eval_all<U8>(tile, wbase) : st.template eval<U8>(tile, wbase);
+            // Replay in stage order: lane k accumulates p_0 .. p_k one after the other -- the same
+            // additions in the same order as the reference's running `hs +=` -- so it ends up
+            // with the score the rejection test of stage rs+k sees.
+            // (ripple through the wave with DPP wave_shr:1 -- lane k takes lane k-1's running sum
+            // and adds its own p; after step j lanes 0..j are final and later steps recompute the
+            // same value, so 63 steps settle every lane)
+            // Lane 0 folds the incoming score into its addend (0 + x == x exactly), so the shifted-in
+            // value of the out-of-range lane can be the DPP zero (bound_ctrl) and each step is ONE
+            // v_add_f32 with a wave_shr:1 source.
+            pk[w] = lane == 0 ? h[w] + p : p;
+            hk[w] = pk[w];
+        }
+        // Most windows are rejected within a few stages, so the ripple runs in blocks of 8 steps and stops
+        // at the first block whose settled lanes hold a rejection: the lowest such lane is the first
+        // rejecting stage (every earlier stage is settled and passed).  (A window that is done keeps rippling
+        // beside its partner: its settled lanes recompute the same sums, its verdict is frozen.)
+        unsigned long long rmask[W];
+        bool done[W];
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                rmask[w] = 0ull;
-                done[w] = false;
-            }
-            for (int settled = 1;;) {                            // lanes [0, settled) hold their final sums
+        for (int w = 0; w < W; ++w) {
+            rmask[w] = 0ull;
+            done[w] = false;
+        }
+        for (int settled = 1;;) {                            // lanes [0, settled) hold their final sums
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-#pragma unroll
-                    for (int w = 0; w < W; ++w) {
-                        int prev = __builtin_amdgcn_update_dpp(0, __float_as_int(hk[w]), 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-                        hk[w] = __int_as_float(prev) + pk[w];
-                    }
-                }
-                settled += 8;
-                const int upto = settled < nvalid ? settled : nvalid;
-                bool all = true;
+            for (int j = 0; j < 8; ++j) {
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
-                    if (!done[w]) {
-                        rmask[w] = __ballot((lane < upto) && (st.theta != -INFINITY) && !(hk[w] >= st.theta));
-                        done[w] = rmask[w] || settled >= nvalid;
-                    }
-                    all = all && done[w];
+                    int prev = __builtin_amdgcn_update_dpp(0, __float_as_int(hk[w]), 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+                    hk[w] = __int_as_float(prev) + pk[w];
                 }
-                if (all) break;
             }
+            settled += 8;
+            const int upto = settled < nvalid ? settled : nvalid;
+            bool all = true;
 #pragma unroll
             for (int w = 0; w < W; ++w) {
-                const int last = rmask[w] ? (int)__builtin_ctzll(rmask[w]) : nvalid - 1;   // last stage entered
-                entered_t += lane <= last ? 1u : 0u;
-                if (!rmask[w]) {
-                    float hl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hk[w]), nvalid - 1));
-                    if (lane == 0) queue[n_out * qs] = make_uint2((uint32_t)pos[w], __float_as_uint(hl));   // n_out <= i + w: entries read above
-                    ++n_out;
+                if (!done[w]) {
+                    rmask[w] = __ballot((lane < upto) && (st.theta != -INFINITY) && !(hk[w] >= st.theta));
+                    done[w] = rmask[w] || settled >= nvalid;
+                }
+                all = all && done[w];
+            }
+            if (all) break;
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const int last = rmask[w] ? (int)__builtin_ctzll(rmask[w]) : nvalid - 1;   // last stage entered
+            entered += lane <= last ? 1u : 0u;                                         // (lanes >= nvalid never count: last < nvalid)
+            rej[w] = rmask[w] != 0ull;
+            h[w] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hk[w]), nvalid - 1));
+        }
+    };
+    // The ripple is a chain of dependent vector instructions: on a SIMD that seven other waves keep busy it advances one
+    // step per round of the issue arbiter -- a 64-stage pass then takes thousands of cycles while the rest of the
+    // workgroup waits at the final barrier.  Raised priority puts the chain's next instruction in front (it issues few).
+    __builtin_amdgcn_s_setprio(WB_TAIL_PRIO);
+    if (scatter) {
+        // The workgroup's few survivors sit in ONE list: every wave claims the next two entries (an LDS ticket) and
+        // takes them through ALL remaining stages, then claims again -- the waves finish within one window of each other
+        // whatever the survivors cost (dealt out in fixed shares, the wave with the longest-lived windows kept the other
+        // seven waiting at the final barrier for a fifth of the workgroup's lifetime).  A window that passes the last
+        // stage is appended to the output right here (one atomic each: they are rare).
+        for (;;) {
+            uint32_t i0 = 0;
+            if (lane == 0) i0 = atomicAdd(ticket, 2u);
+            const int i = __builtin_amdgcn_readfirstlane((int)i0);
+            if (i >= dyn_total) break;
+            const bool two = i + 1 < dyn_total;
+            int pos[2];
+            float h[2];
+            bool alive[2] = {true, two};
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const uint2 e = dyn_list[two || w == 0 ? i + w : i];     // same entry in every lane
+                pos[w] = __builtin_amdgcn_readfirstlane((int)e.x);
+                h[w] = __uint_as_float(e.y);
+            }
+            for (int rs = t_begin; rs < T && (alive[0] || alive[1]); rs += 64) {
+                const int nvalid = T - rs < 64 ? T - rs : 64;
+                const Stage<D> st = lane_stage(rs);
+                uint32_t entered_t = 0;
+                bool rej[2] = {false, false};
+                if (alive[0] && alive[1]) {
+                    pass(WbInt<2>{}, st, nvalid, pos, h, rej, entered_t);
+                } else {
+                    const int k = alive[0] ? 0 : 1;
+                    pass(WbInt<1>{}, st, nvalid, pos + k, h + k, rej + k, entered_t);
+                }
+                if (entered_t) atomicAdd(&hist[rs + lane], entered_t);
+                alive[0] = alive[0] && !rej[0];
+                alive[1] = alive[1] && !rej[1];
+            }
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                if (!alive[w]) continue;                              // wave-uniform
+                if (lane == 0) {
+                    const uint32_t slot = atomicAdd(a.det_count + shard, 1u);
+                    if (slot < a.det_cap) {
+                        WbDet d;
+                        d.image = b;
+                        d.level = tile_d.level;
+                        d.r = (uint16_t)(r0 + (pos[w] >> 6));
+                        d.c = (uint16_t)(c0 + (pos[w] & 63));
+                        d.score = h[w];
+                        a.det[(size_t)shard * a.det_cap + slot] = d;
+                    }
                 }
             }
-        };
-        int i = 0;
-        if constexpr (WB_TAIL_W == 2)
-            for (; i + 1 < n_q; i += 2) windows(WbInt<2>{}, i);
-        for (; WB_TAIL_W != 2 && i + 1 < n_q; ++i) windows(WbInt<1>{}, i);
-        if (i < n_q) windows(WbInt<1>{}, i);
-        if (entered_t) atomicAdd(&hist[t], entered_t);           // (lanes >= nvalid never count: last < nvalid)
-        n_q = n_out;
+        }
+    } else {
+        // a wave's own queue (it left the segments with a few windows): pass by pass, the survivors re-packed in place
+        for (int rs = t_begin; rs < T && n_q > 0; rs += 64) {
+            const int nvalid = T - rs < 64 ? T - rs : 64;
+            const Stage<D> st = lane_stage(rs);
+            int n_out = 0;
+            uint32_t entered_t = 0;                              // windows that entered stage rs + lane in this pass
+            auto windows = [&](auto w_tag, int i) {
+                constexpr int W = decltype(w_tag)::value;
+                int pos[W];
+                float h[W];
+                bool rej[W];
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const uint2 e = queue[i + w];                    // same entry in every lane
+                    pos[w] = __builtin_amdgcn_readfirstlane((int)e.x);
+                    h[w] = __uint_as_float(e.y);
+                }
+                pass(w_tag, st, nvalid, pos, h, rej, entered_t);
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    if (rej[w]) continue;
+                    if (lane == 0) queue[n_out] = make_uint2((uint32_t)pos[w], __float_as_uint(h[w]));   // n_out <= i + w: entries read above
+                    ++n_out;
+                }
+            };
+            int i = 0;
+            if constexpr (WB_TAIL_W == 2)
+                for (; i + 1 < n_q; i += 2) windows(WbInt<2>{}, i);
+            for (; WB_TAIL_W != 2 && i + 1 < n_q; ++i) windows(WbInt<1>{}, i);
+            if (i < n_q) windows(WbInt<1>{}, i);
+            if (entered_t) atomicAdd(&hist[rs + lane], entered_t);
+            n_q = n_out;
+        }
     }
 
+    __builtin_amdgcn_s_setprio(0);
     WB_STAMP(5);
     if (a.dbg & 32) return;
     // ---- epilogue: the wave queues now hold the windows alive after stage T-1.  Every wave that still holds some --
     //      few do -- reserves their slots in one of the sharded output buffers itself (one returning atomic per such
     //      wave, in flight across the barrier below) and copies its records out: no count exchange, no second barrier,
     //      nobody waits for another wave's atomic.  (The order of the records inside a shard was never defined.)
-    const uint32_t shard = blockIdx.x % WB_DET_SHARDS;
     uint32_t slot0 = 0;
     if (n_q > 0 && lane == 0) slot0 = atomicAdd(a.det_count + shard, (uint32_t)n_q);
     __syncthreads();                                          // every wave's per-stage counts are in hist
@@ -870,7 +963,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
         const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
         WbDet *dst = a.det + (size_t)shard * a.det_cap;
         for (int i = lane; i < n_q; i += 64) {
-            uint2 e = queue[i * qs];
+            uint2 e = queue[i];
             if (o + i < a.det_cap) {
                 WbDet d;
                 d.image = b;
