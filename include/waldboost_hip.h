@@ -188,6 +188,12 @@ int wb_channel_func_info(int channel_func, int *n_channels, int *chn_dtype);
 int wb_octaves_launch(void *stream, const void *img, int dtype, int batch, int H, int W,
                       int64_t img_stride, void *oct, int64_t oct_stride, const int64_t *oct_off,
                       int n_oct, uint32_t *minmax);
+/* The same, and the launch's first workgroup also zeroes zero[0 .. zero_words): accumulators a LATER kernel of the step
+ * adds into (the cascade's shard counters and alive[] statistics) -- with wb_cascade_launch_z a step needs no memset
+ * launch at all.  Nothing else may touch those words while this launch runs. */
+int wb_octaves_launch_z(void *stream, const void *img, int dtype, int batch, int H, int W,
+                        int64_t img_stride, void *oct, int64_t oct_stride, const int64_t *oct_off,
+                        int n_oct, uint32_t *minmax, uint32_t *zero, int zero_words);
 
 /* All levels of all images: bilinear resize (fp64) -> channel function (grad_hist: Sobel
  * gradients -> 4 oriented channels with fp64 projection) -> shrink -> 3x3 smooth, fused per tile.
@@ -301,6 +307,13 @@ int wb_cascade_launch(void *stream, const WbModel *model, const void *chn, int c
                       int64_t chn_stride, int batch, const WbLevel *levels, int n_levels,
                       const WbTile *tiles, int n_tiles, WbDet *det, uint32_t *det_count,
                       uint32_t shard_capacity, uint32_t *alive);
+/* The same, and the launch's first workgroup also zeroes zero[0 .. zero_words): the octaves' (min, max) keys, which
+ * nothing of this step reads any more once the channel kernel has finished -- ready for the next step's
+ * wb_octaves_launch(_z). */
+int wb_cascade_launch_z(void *stream, const WbModel *model, const void *chn, int chn_dtype,
+                        int64_t chn_stride, int batch, const WbLevel *levels, int n_levels,
+                        const WbTile *tiles, int n_tiles, WbDet *det, uint32_t *det_count,
+                        uint32_t shard_capacity, uint32_t *alive, uint32_t *zero, int zero_words);
 
 /* The valid records of all shards of a detection buffer (as wb_cascade_launch fills it), packed back to back:
  *   packed  dev int32, 16-byte aligned: a 4-word header {valid records in all shards, fullest shard's count

@@ -188,3 +188,37 @@ def test_captured_step_refuses_to_replay_after_the_engine_reallocated():
     g2.replay()
     torch.cuda.synchronize()
     assert_image_matches(engine_results(e, e._casc_state(dm), len(M))[0], ref)
+
+
+def test_memset_free_steps_survive_other_users_of_the_engine():
+    """A step holds no memset: the octave kernel resets what the cascade accumulates into, the cascade resets the
+    octaves' (min, max) keys for the next step.  Anything else that runs the octaves on the same engine in between -- a
+    pyramid for a caller, Model.detect's cached engine handed to channel_pyramid -- leaves dirty keys behind; the next
+    replay must notice (a stale maximum would widen the resize's clip range silently)."""
+    import torch
+    from waldboost_amd.engine import PyramidEngine
+    M = wb.load(os.path.join(GOLDEN, "mixed_d2_T24.pb"))
+    dm = M.device_cascade()
+    H, W = 200, 264
+    bright, dark = synth_image(H, W, 31), (synth_image(H, W, 32) // 3).astype(np.uint8)     # different (min, max)
+    assert bright.max() > dark.max() + 50
+    e = PyramidEngine(H, W, np.uint8, 2, 8, 1, batch=1)
+    e.load_images(bright)
+    g = e.capture(dm)
+    g.replay()
+    torch.cuda.synchronize()
+    assert_image_matches(engine_results(e, e._casc_state(dm), len(M))[0], oracle_detect(M, bright))
+    e.run_channels()                               # someone else's pyramid of the BRIGHT image: keys left dirty
+    e.load_images(dark)
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    assert_image_matches(engine_results(e, e._casc_state(dm), len(M))[0], oracle_detect(M, dark))
+    # the same through the API: Model.detect's replayed graph and channel_pyramid share the cached engine
+    for _ in range(3):
+        M.detect(bright)
+    lv = list(wb.channels.channel_pyramid(bright, M.channel_opts))
+    ref = oracle_detect(M, dark)
+    res = M.detect_raw(dark)
+    assert np.array_equal(res["alive"], ref["alive"]) and np.array_equal(bits(res["scores"]), bits(ref["scores"]))
+    assert len(lv) == ref["alive"].shape[0]

@@ -47,6 +47,8 @@ SYMBOLS = {
     "wb_channel_func_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "wb_octaves_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, C.c_int64,
                                     C.POINTER(C.c_int64), C.c_int, _P]),
+    "wb_octaves_launch_z": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, C.c_int64,
+                                      C.POINTER(C.c_int64), C.c_int, _P, _P, C.c_int]),
     "wb_channels_launch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int,
                                      _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P, C.c_int64,
                                      _P, _P, C.c_int64]),
@@ -64,6 +66,8 @@ SYMBOLS = {
     "wb_rankgroup_destroy": (C.c_int, [_P]),
     "wb_cascade_launch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P,
                                     C.c_uint32, _P]),
+    "wb_cascade_launch_z": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P,
+                                      C.c_uint32, _P, _P, C.c_int]),
     "wb_tree_eval_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P, _P, _P, _P, _P,
                                       C.c_int, _P]),
     "wb_gather_samples_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),

@@ -64,9 +64,13 @@ struct GenArgs {
     uint32_t *det_count;
     uint32_t det_cap;
     uint32_t *alive;
+    uint32_t *zero;
+    int zero_words;
 };
 
 __global__ __launch_bounds__(256) void cascade_generic_kernel(GenArgs a) {
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < a.zero_words; i += 256) a.zero[i] = 0u;      // (see cascade_tile_body)
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     uint32_t *hist = reinterpret_cast<uint32_t *>(gsm);                       // T counters
     uint2 *list = reinterpret_cast<uint2 *>(gsm + (((size_t)a.T * 4 + 15) & ~(size_t)15));   // 256 entries
@@ -362,6 +366,15 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
                                  int64_t chn_stride, int batch, const WbLevel *levels, int n_levels,
                                  const WbTile *tiles, int n_tiles, WbDet *det, uint32_t *det_count,
                                  uint32_t shard_capacity, uint32_t *alive) {
+    return wb_cascade_launch_z(stream, model, chn, chn_dtype, chn_stride, batch, levels, n_levels, tiles, n_tiles, det, det_count,
+                               shard_capacity, alive, nullptr, 0);
+}
+
+extern "C" int wb_cascade_launch_z(void *stream, const WbModel *model, const void *chn, int chn_dtype,
+                                   int64_t chn_stride, int batch, const WbLevel *levels, int n_levels,
+                                   const WbTile *tiles, int n_tiles, WbDet *det, uint32_t *det_count,
+                                   uint32_t shard_capacity, uint32_t *alive, uint32_t *zero, int zero_words) {
+    WB_REQUIRE(zero_words == 0 || (zero && zero_words > 0), "wb_cascade_launch_z: zero_words without a pointer");
     WB_REQUIRE(model && chn && levels && tiles && det_count, "wb_cascade_launch: null pointer");
     WB_REQUIRE(det || shard_capacity == 0, "wb_cascade_launch: det is null but capacity > 0");
     WB_REQUIRE(batch >= 1 && batch <= 65535, "wb_cascade_launch: batch %d out of range", batch);
@@ -391,6 +404,8 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
     a.det_count = det_count;
     a.det_cap = shard_capacity;
     a.alive = alive;
+    a.zero = zero;
+    a.zero_words = zero_words;
     a.n_tiles = n_tiles;
     static const int dbg = getenv("WB_CASC_DBG") ? atoi(getenv("WB_CASC_DBG")) : 0;
     a.dbg = dbg;
@@ -418,6 +433,7 @@ extern "C" int wb_cascade_launch(void *stream, const WbModel *model, const void 
         g.node_off = model->g_node_off; g.feat = model->g_feat; g.left = model->g_left; g.right = model->g_right;
         g.thr = model->g_thr; g.pred = model->g_pred; g.theta = model->g_theta;
         g.det = det; g.det_count = det_count; g.det_cap = shard_capacity; g.alive = alive;
+        g.zero = zero; g.zero_words = zero_words;
         size_t lds = (((size_t)g.T * 4 + 15) & ~(size_t)15) + 256 * 8;
         WB_REQUIRE(lds <= 64 * 1024, "wb_cascade_launch: %d stages exceed the generic kernel's LDS", g.T);
         hipLaunchKernelGGL(cascade_generic_kernel, grid, dim3(256), lds, st, g);

@@ -103,6 +103,8 @@ struct CascArgs {
     int n_tiles;
     int spar_wg;                // the whole tile goes stage-parallel after phase A when it holds at most this many windows
     int spar[4];                // stage-parallel tail entry: (t >= spar[0] && n <= spar[1]) || (t >= spar[2] && n <= spar[3])
+    uint32_t *zero;             // words the NEXT step's first kernel accumulates into (the octaves' min / max keys): reset here
+    int zero_words;
     int dbg;                    // diagnostics (WB_CASC_DBG): 1 = skip the tile load, 2 = stop after the load
 };
 
@@ -326,6 +328,10 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     uint32_t *wcnt2 = wcnt + WAVES;
     uint32_t *ticket = wcnt2 + WAVES;           // next unclaimed entry of the workgroup's survivor list (the stage-parallel tail)
     if (tid == 0) *ticket = 0u;                 // (visible behind the tile load's barrier)
+    // (nothing of this step reads the octaves' min / max keys any more -- the channel kernel has finished: the first
+    // workgroup resets them for the next step's octave kernel, which then needs no memset launch in front of it)
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = tid; i < a.zero_words; i += NT) a.zero[i] = 0u;
     if constexpr (BAKED) {
         // the specialised stages address LDS by number: the dynamic region must start at LDS address 0
         if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();

@@ -74,7 +74,12 @@ struct OctDims {
 // grid = (blocks_x * blocks_y, batch); block = 256 threads
 template <typename T>
 __global__ __launch_bounds__(256) void octaves_block_kernel(const T *img, int64_t img_stride, T *oct, int64_t oct_stride,
-                                                            OctDims d, int n_oct, int blocks_x, uint32_t *minmax) {
+                                                            OctDims d, int n_oct, int blocks_x, uint32_t *minmax,
+                                                            uint32_t *zero, int zero_words) {
+    // words a LATER kernel of the step accumulates into (the cascade's counters and statistics): nobody touches them while
+    // this kernel runs, so its first workgroup resets them -- a step then needs no memset launch of its own
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < zero_words; i += 256) zero[i] = 0u;
     constexpr int OB = Blk<T>::OB, OB_LEVELS = Blk<T>::LEVELS;
     __shared__ __attribute__((aligned(16))) T bufA[OB * OB];
     __shared__ T bufB[(OB / 2) * (OB / 2)];
@@ -300,7 +305,9 @@ __device__ inline double wrap_int(double s, int bits, int sgn) {
 }
 
 __global__ __launch_bounds__(256) void minmax_f64_kernel(const double *img, int64_t img_stride, int64_t n, int n_oct,
-                                                         unsigned long long *minmax) {
+                                                         unsigned long long *minmax, uint32_t *zero, int zero_words) {
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < zero_words; i += 256) zero[i] = 0u;          // (see octaves_block_kernel)
     const double *src = img + (int64_t)blockIdx.y * img_stride;
     unsigned long long nlo = 0, hi = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(256) void pool_f64_kernel(const double *src_base, i
 }
 
 int launch_octaves_f64(hipStream_t st, const double *img, int dtype, int batch, int H, int W, int64_t img_stride, double *oct,
-                       int64_t oct_stride, const int64_t *oct_off, int n_oct, unsigned long long *minmax) {
+                       int64_t oct_stride, const int64_t *oct_off, int n_oct, unsigned long long *minmax, uint32_t *zero, int zero_words) {
     int bits = 0, sgn = 0;
     switch (dtype) {
         case WB_DTYPE_F64: break;
@@ -361,7 +368,7 @@ int launch_octaves_f64(hipStream_t st, const double *img, int dtype, int batch, 
     const int64_t n0 = (int64_t)H * W;
     int blocks = (int)((n0 + 255) / 256);
     blocks = blocks > 2048 ? 2048 : blocks;
-    hipLaunchKernelGGL(minmax_f64_kernel, dim3(blocks, batch), dim3(256), 0, st, img, img_stride, n0, n_oct, minmax);
+    hipLaunchKernelGGL(minmax_f64_kernel, dim3(blocks, batch), dim3(256), 0, st, img, img_stride, n0, n_oct, minmax, zero, zero_words);
     int sh = H, sw = W;
     for (int k = 1; k < n_oct; ++k) {
         const int oh = sh >> 1, ow = sw >> 1;
@@ -378,7 +385,7 @@ int launch_octaves_f64(hipStream_t st, const double *img, int dtype, int batch, 
 
 template <typename T>
 int launch_octaves(hipStream_t st, const T *img, int batch, int H, int W, int64_t img_stride, T *oct,
-                   int64_t oct_stride, const int64_t *oct_off, int n_oct, uint32_t *minmax) {
+                   int64_t oct_stride, const int64_t *oct_off, int n_oct, uint32_t *minmax, uint32_t *zero, int zero_words) {
     OctDims d;
     int h = H, w = W;
     for (int k = 0; k < n_oct; ++k) {
@@ -391,7 +398,7 @@ int launch_octaves(hipStream_t st, const T *img, int batch, int H, int W, int64_
     constexpr int OB = Blk<T>::OB, OB_LEVELS = Blk<T>::LEVELS;
     const int bx = (W + OB - 1) / OB, by = (H + OB - 1) / OB;
     hipLaunchKernelGGL(octaves_block_kernel<T>, dim3(bx * by, batch), dim3(256), 0, st, img, img_stride, oct, oct_stride,
-                       d, n_oct, bx, minmax);
+                       d, n_oct, bx, minmax, zero, zero_words);
     if (n_oct > OB_LEVELS + 1) {
         size_t px = (size_t)d.h[OB_LEVELS] * d.w[OB_LEVELS];
         size_t lds = (px + px / 4 + 16) * sizeof(T);
@@ -413,7 +420,14 @@ int launch_octaves(hipStream_t st, const T *img, int batch, int H, int W, int64_
 extern "C" int wb_octaves_launch(void *stream, const void *img, int dtype, int batch, int H, int W,
                                  int64_t img_stride, void *oct, int64_t oct_stride, const int64_t *oct_off,
                                  int n_oct, uint32_t *minmax) {
+    return wb_octaves_launch_z(stream, img, dtype, batch, H, W, img_stride, oct, oct_stride, oct_off, n_oct, minmax, nullptr, 0);
+}
+
+extern "C" int wb_octaves_launch_z(void *stream, const void *img, int dtype, int batch, int H, int W,
+                                   int64_t img_stride, void *oct, int64_t oct_stride, const int64_t *oct_off,
+                                   int n_oct, uint32_t *minmax, uint32_t *zero, int zero_words) {
     WB_REQUIRE(img && minmax, "wb_octaves_launch: null pointer");
+    WB_REQUIRE(zero_words == 0 || (zero && zero_words > 0), "wb_octaves_launch_z: zero_words without a pointer");
     WB_REQUIRE(batch >= 1 && batch <= 65535 && H >= 1 && W >= 1, "wb_octaves_launch: bad shape batch=%d H=%d W=%d", batch, H, W);
     WB_REQUIRE(n_oct >= 1 && n_oct <= WB_MAX_OCTAVES, "wb_octaves_launch: n_oct=%d out of range", n_oct);
     WB_REQUIRE(n_oct == 1 || (oct && oct_off), "wb_octaves_launch: octave buffer missing");
@@ -425,12 +439,12 @@ extern "C" int wb_octaves_launch(void *stream, const void *img, int dtype, int b
     }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == WB_DTYPE_U8)
-        return launch_octaves<uint8_t>(st, (const uint8_t *)img, batch, H, W, img_stride, (uint8_t *)oct, oct_stride, oct_off, n_oct, minmax);
+        return launch_octaves<uint8_t>(st, (const uint8_t *)img, batch, H, W, img_stride, (uint8_t *)oct, oct_stride, oct_off, n_oct, minmax, zero, zero_words);
     if (dtype == WB_DTYPE_F32)
-        return launch_octaves<float>(st, (const float *)img, batch, H, W, img_stride, (float *)oct, oct_stride, oct_off, n_oct, minmax);
+        return launch_octaves<float>(st, (const float *)img, batch, H, W, img_stride, (float *)oct, oct_stride, oct_off, n_oct, minmax, zero, zero_words);
     if (wb_dtype_held_f64(dtype))
         return launch_octaves_f64(st, (const double *)img, dtype, batch, H, W, img_stride, (double *)oct, oct_stride, oct_off, n_oct,
-                                  reinterpret_cast<unsigned long long *>(minmax));
+                                  reinterpret_cast<unsigned long long *>(minmax), zero, zero_words);
     wb_set_error("wb_octaves_launch: unsupported image dtype code %d", dtype);
     return WB_ERR_UNSUPPORTED;
 }

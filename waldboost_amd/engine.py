@@ -23,6 +23,7 @@ _NO_RANKS = bool(os.environ.get("WB_NO_RANKS"))     # diagnostic: float32 channe
 # Model-specialised cascade kernels (csrc/wb_jit.hip): a cascade that has been scanned this many times on byte tiles is
 # compiled with its stage records as constants (hiprtc, ~2 s once; cached on disk).  WB_CASC_JIT=0: never automatically
 # (DeviceCascade.specialize() still works), WB_CASC_JIT_AFTER=n: after n scans (default 3).
+_NO_FUSED_RESET = bool(os.environ.get("WB_NO_FUSED_RESET"))   # diagnostic: one memset launch per step, as before
 _JIT_AUTO = os.environ.get("WB_CASC_JIT", "1") != "0"
 _JIT_AFTER = int(os.environ.get("WB_CASC_JIT_AFTER", "3"))
 
@@ -304,6 +305,7 @@ class CapturedStep:
         if self.generation != self.engine.generation:
             raise RuntimeError("this captured step is stale: the engine re-allocated its control block or detection "
                                "buffer after the capture (a longer cascade, or a grown detection buffer); capture again")
+        self.engine.ensure_clean_keys()          # (the graph holds no memset: see PyramidEngine.run)
         self.graph.replay()
 
 
@@ -343,6 +345,7 @@ class PyramidEngine:
         self._mm_words = self.batch * max(p.n_oct, 1) * 2 * (2 if self.wide_keys else 1)
         self._alive_words = 0
         self.generation = 0           # bumped whenever a buffer a captured graph may address is re-allocated
+        self._mm_clean = False        # the octaves' (min, max) keys are known to be zero (see run)
         self._alloc_ctrl(0)
         table, total = p.level_table()
         self.chn_stride = int(total)
@@ -455,13 +458,23 @@ class PyramidEngine:
         self.img.copy_(t, non_blocking=True)
 
     # ------------------------------------------------------------------ launches
-    def launch_octaves(self):
+    def launch_octaves(self, zero=None):
+        """zero: a tensor view of accumulator words the launch's first workgroup resets (see run)."""
         p = self.plan
         if p.n_levels == 0 or self.exact_single:
             return
-        nat.check(self.lib.wb_octaves_launch(nat.stream_ptr(), nat.ptr(self.img), self.wb_dtype, self.batch, p.H, p.W,
-                                             p.H * p.W, nat.ptr(self.oct), p.oct_total, self._oct_off, p.n_oct,
-                                             nat.ptr(self.minmax)), "wb_octaves_launch")
+        self._mm_clean = False
+        nat.check(self.lib.wb_octaves_launch_z(nat.stream_ptr(), nat.ptr(self.img), self.wb_dtype, self.batch, p.H, p.W,
+                                               p.H * p.W, nat.ptr(self.oct), p.oct_total, self._oct_off, p.n_oct,
+                                               nat.ptr(self.minmax), nat.ptr(zero), 0 if zero is None else zero.numel()),
+                  "wb_octaves_launch")
+
+    def ensure_clean_keys(self):
+        """A captured step holds no memset (run): before it is replayed the octaves' keys must be zero -- they are, unless
+        something else (a pyramid for a caller, a bare octave launch) has used this engine since the last step."""
+        if not self._mm_clean and not self.exact_single:
+            self.ctrl[: self._mm_words].zero_()
+            self._mm_clean = True
 
     def ranks_for(self, dm):
         """True when the fused detection path applies: grad_hist channels written straight as threshold ranks of
@@ -566,23 +579,28 @@ class PyramidEngine:
             self._casc[key] = stt
         return stt
 
-    def launch_cascade(self, dm, ranks=False, stats=True):
+    def launch_cascade(self, dm, ranks=False, stats=True, zero_keys=False):
         """The cascade scan, adding into the detection counters and (stats) alive[B, L, T] -- reset_step first.
-        ranks=True scans self.rank (written for `dm` by launch_channels) instead of the channel buffer."""
+        ranks=True scans self.rank (written for `dm` by launch_channels) instead of the channel buffer.
+        zero_keys: the launch's first workgroup also resets the octaves' (min, max) keys for the next step (see run)."""
         stt = self._casc_state(dm)
         if stt["n_tiles"] == 0:
             return stt
         if ranks and self.rank_owner is not dm.rank_key:
             raise RuntimeError("the rank buffer does not hold this cascade's ranks (launch_channels(rank_dm=...) first)")
         dm.note_scan(nat.WB_DTYPE_RANK8 if ranks else self.spec.wb_dtype)
-        nat.check(self.lib.wb_cascade_launch(nat.stream_ptr(), dm.handle, nat.ptr(self.rank if ranks else self.chn),
-                                             nat.WB_DTYPE_RANK8 if ranks else self.spec.wb_dtype,
-                                             self.chn_stride,
-                                             self.batch, nat.ptr(self.levels), self.plan.n_levels,
-                                             nat.ptr(stt["tiles"]), stt["n_tiles"],
-                                             nat.ptr(self.detb.recs), nat.ptr(self.detb.counts), self.detb.cap,
-                                             nat.ptr(stt["alive"] if stats else None)),
+        zk = self.ctrl[: self._mm_words] if zero_keys else None
+        nat.check(self.lib.wb_cascade_launch_z(nat.stream_ptr(), dm.handle, nat.ptr(self.rank if ranks else self.chn),
+                                               nat.WB_DTYPE_RANK8 if ranks else self.spec.wb_dtype,
+                                               self.chn_stride,
+                                               self.batch, nat.ptr(self.levels), self.plan.n_levels,
+                                               nat.ptr(stt["tiles"]), stt["n_tiles"],
+                                               nat.ptr(self.detb.recs), nat.ptr(self.detb.counts), self.detb.cap,
+                                               nat.ptr(stt["alive"] if stats else None), nat.ptr(zk),
+                                               0 if zk is None else zk.numel()),
                   "wb_cascade_launch")
+        if zero_keys:
+            self._mm_clean = True
         return stt
 
     def run_cascade(self, dm, ranks=False):
@@ -603,11 +621,26 @@ class PyramidEngine:
         memset and three kernels.  When the cascade has rank tables the channels go to HBM as ranks only."""
         fused = self.ranks_for(dm)
         stt = self._casc_state(dm)
-        self.reset_step(stt, octaves=True)
-        self.launch_octaves()
+        # No memset launch: the octave kernel's first workgroup resets what the CASCADE accumulates into (shard counters,
+        # alive[B, L, T] -- nothing touches them before it), the cascade's first workgroup resets what the next step's
+        # OCTAVE kernel accumulates into (the (min, max) keys -- the channel kernel has finished with them).  The keys
+        # must be zero on entry: ensure_clean_keys (one memset after anything else has used the engine's octaves).
+        if self.exact_single or _NO_FUSED_RESET or stt["n_tiles"] == 0 or self.plan.n_levels == 0:
+            self.reset_step(stt, octaves=True)
+            self.launch_octaves()
+            self.launch_channels(dm if fused else None, floats=not fused)
+            stt["ranks"] = fused
+            return self.launch_cascade(dm, ranks=fused)
+        import torch
+        if not torch.cuda.is_current_stream_capturing():
+            self.ensure_clean_keys()
+        elif not self._mm_clean:
+            raise RuntimeError("capture a step only after an eager one (PyramidEngine.capture does): the octaves' keys must be clean")
+        o = self._mm_words
+        self.launch_octaves(zero=self.ctrl[o: o + nat.WB_DET_SHARDS + stt["alive"].numel()])
         self.launch_channels(dm if fused else None, floats=not fused)
         stt["ranks"] = fused
-        return self.launch_cascade(dm, ranks=fused)
+        return self.launch_cascade(dm, ranks=fused, zero_keys=True)
 
     # ------------------------------------------------------------------ hipGraph
     def capture(self, dm):
@@ -780,6 +813,7 @@ class PyramidEngine:
             # a cascade that is scanned again is worth its specialised kernel -- built now, so that the graph holds it
             dm.note_scan(nat.WB_DTYPE_RANK8 if self.ranks_for(dm) else self.spec.wb_dtype, force=True)
             g = torch.cuda.CUDAGraph()
+            self.ensure_clean_keys()          # (the captured step holds no memset: see run)
             torch.cuda.synchronize()
             with torch.cuda.graph(g):
                 self.run(dm)
@@ -789,6 +823,7 @@ class PyramidEngine:
         if g is None:
             self.run(dm)
             return self.fetch_final(dm, stt)
+        self.ensure_clean_keys()
         g.replay()
         return self.fetch_final(dm, stt, enqueued=True)
 
