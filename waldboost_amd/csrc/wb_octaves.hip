@@ -99,7 +99,73 @@ __global__ __launch_bounds__(256) void octaves_block_kernel(const T *img, int64_
     const int y0 = by * OB, x0 = bx * OB;
     uint32_t nlo = 0u, hi = 0u;
     constexpr int U = 8;
-    if (sizeof(T) == 1 && (W & 3) == 0 && (img_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0) {
+    // bytes, rows 16-byte aligned (the usual image): a thread takes 16 pixels of TWO rows (two 16-byte loads, all of a
+    // block's loads in flight at once), pools them into 8 pixels of octave 1 in registers -- two byte lanes per dword at a
+    // time -- and stores those as two dwords: octave 0 never goes through LDS, octave 1 leaves with 8-byte instead of
+    // 1-byte stores (at batch 1 the kernel is one round of workgroups whose serial depth is the image's octave chain)
+    bool from_regs = false;
+    uint32_t nlo1 = 0u, hi1 = 0u;
+    if constexpr (sizeof(T) == 1) {
+        T *dst1 = obase + (n_oct > 1 ? d.off[1] : 0);
+        from_regs = n_oct > 1 && (W & 15) == 0 && (img_stride & 15) == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0 &&
+                    (d.w[1] & 3) == 0 && (reinterpret_cast<uintptr_t>(dst1) & 3) == 0;
+        if (from_regs) {
+            constexpr int NG = OB / 16, NITEM = (OB / 2) * NG, PER = NITEM / 256;
+            static_assert(NITEM % 256 == 0, "whole items per thread");
+            const int oh = d.h[1], ow = d.w[1];
+            uint4 va[PER], vb[PER];
+            int item_r[PER], item_g[PER];
+            bool ok0[PER], ok1[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int it = tid + k * 256;
+                const int rp = it / NG, g = it - rp * NG;
+                item_r[k] = rp;
+                item_g[k] = g;
+                const int ya = y0 + 2 * rp, yb = ya + 1, x = x0 + 16 * g;
+                ok0[k] = ya < H && x < W;
+                ok1[k] = yb < H && x < W;
+                const int yac = ya < H ? ya : H - 1, ybc = yb < H ? yb : H - 1, xc = x < W ? x : W - 16;
+                va[k] = *reinterpret_cast<const uint4 *>(src + (int64_t)yac * W + xc);
+                vb[k] = *reinterpret_cast<const uint4 *>(src + (int64_t)ybc * W + xc);
+            }
+            uint32_t *lds1 = reinterpret_cast<uint32_t *>(bufB);          // octave 1 of the block: [OB/2][OB/2] bytes
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const uint32_t a[4] = {va[k].x, va[k].y, va[k].z, va[k].w}, b[4] = {vb[k].x, vb[k].y, vb[k].z, vb[k].w};
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) {
+                        const uint32_t pa = (a[j] >> (8 * bb)) & 255u, pb = (b[j] >> (8 * bb)) & 255u;
+                        if (ok0[k]) { nlo = (~pa) > nlo ? (~pa) : nlo; hi = pa > hi ? pa : hi; }
+                        if (ok1[k]) { nlo = (~pb) > nlo ? (~pb) : nlo; hi = pb > hi ? pb : hi; }
+                    }
+                    // two pooled pixels per dword: the byte pairs summed in 16-bit lanes ((a+b+c+d) & 255) >> 2
+                    const uint32_t sum = (a[j] & 0x00ff00ffu) + ((a[j] >> 8) & 0x00ff00ffu) + (b[j] & 0x00ff00ffu) + ((b[j] >> 8) & 0x00ff00ffu);
+                    o[j] = ((sum >> 2) & 0x3fu) | (((sum >> 18) & 0x3fu) << 8);
+                }
+                const uint32_t out0 = o[0] | (o[1] << 16), out1 = o[2] | (o[3] << 16);
+                const int rp = item_r[k], g = item_g[k];
+                lds1[(rp * (OB / 2) + 8 * g) / 4] = out0;
+                lds1[(rp * (OB / 2) + 8 * g) / 4 + 1] = out1;
+                const int oy = (y0 >> 1) + rp, ox = (x0 >> 1) + 8 * g;
+                if (oy < oh && ox < ow) {                                  // (ow % 4 == 0 and ox % 8 == 0: whole dwords in or out)
+                    uint32_t *gp = reinterpret_cast<uint32_t *>(dst1 + (int64_t)oy * ow + ox);
+                    gp[0] = out0;
+                    if (ox + 4 < ow) gp[1] = out1;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const uint32_t pv = ((q < 4 ? out0 : out1) >> (8 * (q & 3))) & 255u;
+                        if (ox + q < ow) { nlo1 = (~pv) > nlo1 ? (~pv) : nlo1; hi1 = pv > hi1 ? pv : hi1; }
+                    }
+                }
+            }
+        }
+    }
+    if (from_regs) {
+    } else if (sizeof(T) == 1 && (W & 3) == 0 && (img_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0) {
         constexpr int DW = OB / 4;                                   // dwords per block row
         const uint32_t *src32 = reinterpret_cast<const uint32_t *>(src);
         uint32_t *lds32 = reinterpret_cast<uint32_t *>(bufA);
@@ -172,13 +238,15 @@ __global__ __launch_bounds__(256) void octaves_block_kernel(const T *img, int64_
     for (int j = 0; j < 2 * (OB_LEVELS + 1); ++j) pmm[j] = 0u;
     pmm[0] = nlo;
     pmm[1] = hi;
+    pmm[2] = nlo1;                       // (octave 1 straight from registers: see above)
+    pmm[3] = hi1;
 
     // ---- octaves 1..7: pool LDS -> LDS (+ global), ping-pong between bufA and bufB
-    T *cur = bufA;
-    T *nxt = bufB;
-    int side = OB;                       // side of `cur`
+    T *cur = from_regs ? bufB : bufA;
+    T *nxt = from_regs ? bufA : bufB;
+    int side = from_regs ? OB / 2 : OB;  // side of `cur`
     const int kmax = n_oct - 1 < OB_LEVELS ? n_oct - 1 : OB_LEVELS;
-    for (int k = 1; k <= kmax; ++k) {
+    for (int k = from_regs ? 2 : 1; k <= kmax; ++k) {
         const int ns = side >> 1;
         const int oh = d.h[k], ow = d.w[k];
         const int oy0 = y0 >> k, ox0 = x0 >> k;
