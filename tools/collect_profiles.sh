@@ -6,7 +6,9 @@ set -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=${1:-gpurun_out/prof}
-rm -rf $O && mkdir -p $O
+PART=${PART:-12}
+mkdir -p $O
+if [[ $PART == *1* ]]; then
 timeout -k 10 500 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -5 $O/bench_default.err; exit 1; }
 echo "default bench done"
 timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_flags.json 2>> $O/bench_default.err || exit 1
@@ -22,6 +24,8 @@ timeout -k 10 300 python3 tools/bench_cfg5.py > $O/bench_cfg5.txt 2>> $O/bench_d
 timeout -k 10 300 python3 tools/bench_next_rows.py > $O/bench_next_rows.txt 2>> $O/bench_default.err || exit 1
 timeout -k 10 300 python3 tools/detect_breakdown.py > $O/model_detect_host_timeline.txt 2>> $O/bench_default.err || exit 1
 echo "bench lines done"
+fi
+if [[ $PART == *2* ]]; then
 S="--no-cpu-baseline --no-through-api --repeats 2"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_default --output-format csv -- python3 bench.py $S > $O/stats_default.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_streams1 --output-format csv -- python3 bench.py $S --streams 1 > $O/stats_streams1.log 2>&1 || exit 1
@@ -38,4 +42,6 @@ for d in stats_default stats_streams1 stats_batch64 stats_cfg5; do
 done
 rm -rf $O/stats_default $O/stats_streams1 $O/stats_batch64 $O/stats_cfg5 $O/pmc_fetch $O/pmc_write
 tools/collect_sq.sh $O/sq > /dev/null 2>&1 && cp $O/sq/sq_counters.txt $O/sq/sq_counters.json $O/ && rm -rf $O/sq
+tools/phase_insts.sh $O/ph > $O/phase_instruction_counts.txt 2>&1; rm -rf $O/ph
+fi
 ls -la $O

@@ -51,12 +51,14 @@ def detect(image, *models, channel_opts=None, response_scale=None):
     group = None
     if spec.key == "grad_hist" and not _engine._NO_RANKS and all(m.shape[2] == spec.n_channels for m in models):
         group = _engine.rank_group([m.device_cascade() for m in models])
+    views = group.views if group is not None else [None] * len(models)
     if group is not None:
         eng.run_channels(rank_dm=group.views[0], floats=False)
-        res = [m.scan_engine(eng, view=v) for m, v in zip(models, group.views)]
     else:
         eng.run_channels()
-        res = [m.scan_engine(eng) for m in models]
+    # (one wait per model: enqueueing every model's scan and read-back first and waiting once was measured SLOWER --
+    # 0.80 against 0.69 ms per call for two 128-stage models at 1080p)
+    res = [m.scan_engine(eng, view=v) for m, v in zip(models, views)]
     # level-major, then model, then row-major: every model's result is ordered by (level, r, c) already, so ONE stable sort
     # by (level, model) gives the reference's nested-loop order (a Python loop over levels x models building Boxes was
     # 0.8 ms of a 1.1 ms call)

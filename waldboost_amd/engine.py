@@ -367,7 +367,7 @@ class PyramidEngine:
         self.det_capacity = int(det_capacity)
         self._h_packed = self._h_alive = self._fetch_ev = None
         self._mm_host = None
-        self._final = self._h_final = self._h_final_views = self._inv_scales_d = self._final_dims = None
+        self._inv_scales_d = self._final_dims = None
         self._alloc_det()
         if exact_single:
             # a channel function on a bare image: no resize happens, so the clip range is (-inf, +inf)
@@ -744,29 +744,31 @@ class PyramidEngine:
             self._final_dims = (ok and mu <= 16384 and mv <= 16384, mu, mv)
         if not self._final_dims[0]:
             return False
-        if self._final is None:
-            P = self._FETCH_ROWS
-            nbytes = 16 + P * 28
-            self._final = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
-            self._h_final = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        if self._inv_scales_d is None:
             self._inv_scales_d = torch.from_numpy(self.inv_scales()).to(self.dev)
             self._fetch_ev = self._fetch_ev or torch.cuda.Event()
-            h = self._h_final.numpy()
-            self._h_final_views = (h[:16].view(np.int32), h[16:16 + 8 * P].view(np.uint64),
-                                   h[16 + 8 * P:16 + 24 * P].view(np.float32).reshape(P, 4), h[16 + 24 * P:].view(np.float32))
         return True
 
     def _final_enqueue(self, dm, stt):
-        """wb_det_finish_launch + the two read-back copies into page-locked memory (no synchronisation)."""
+        """wb_det_finish_launch + the two read-back copies into page-locked memory (no synchronisation).  The buffers
+        belong to the cascade's scan state: several cascades can be scanned back to back on one engine (waldboost.detect)
+        and read back with ONE wait -- the shared detection buffer is free again as soon as this launch has run."""
         import torch
-        if self._h_alive is None or self._h_alive.shape != stt["alive"].shape:
-            self._h_alive = torch.empty(stt["alive"].shape, dtype=torch.int32).pin_memory()
+        if "final" not in stt:
+            P = self._FETCH_ROWS
+            nbytes = 16 + P * 28
+            stt["final"] = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            stt["h_final"] = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+            h = stt["h_final"].numpy()
+            stt["h_final_views"] = (h[:16].view(np.int32), h[16:16 + 8 * P].view(np.uint64),
+                                    h[16 + 8 * P:16 + 24 * P].view(np.float32).reshape(P, 4), h[16 + 24 * P:].view(np.float32))
+            stt["h_alive"] = torch.empty(stt["alive"].shape, dtype=torch.int32).pin_memory()
         nat.check(self.lib.wb_det_finish_launch(nat.stream_ptr(), nat.ptr(self.detb.recs), nat.ptr(self.detb.counts),
                                                 self.detb.cap, nat.ptr(self._inv_scales_d), self.plan.n_levels,
                                                 self._final_dims[1], self._final_dims[2], dm.m, dm.n,
-                                                nat.ptr(self._final), self._FETCH_ROWS), "wb_det_finish_launch")
-        self._h_final.copy_(self._final, non_blocking=True)
-        self._h_alive.copy_(stt["alive"], non_blocking=True)
+                                                nat.ptr(stt["final"]), self._FETCH_ROWS), "wb_det_finish_launch")
+        stt["h_final"].copy_(stt["final"], non_blocking=True)
+        stt["h_alive"].copy_(stt["alive"], non_blocking=True)
 
     def fetch_final(self, dm, stt, enqueued=False):
         """fetch() for Model.detect on ONE image: wb_det_finish_launch leaves sort keys, boxes and scores of all
@@ -785,7 +787,7 @@ class PyramidEngine:
             enqueued = False
             self._fetch_ev.record()
             self._fetch_ev.synchronize()
-            hdr, keys, boxes, scores = self._h_final_views
+            hdr, keys, boxes, scores = stt["h_final_views"]
             total, worst = int(hdr[0]), int(hdr[1])
             if worst <= self.detb.cap:
                 break
@@ -794,7 +796,7 @@ class PyramidEngine:
             stt = self.run_cascade(dm, ranks=stt.get("ranks", False))
         if total > P:
             return None
-        alive = self._h_alive.numpy()[:, :, :T].astype(np.int64)
+        alive = stt["h_alive"].numpy()[:, :, :T].astype(np.int64)
         return keys[:total], boxes, scores, alive
 
     def detect_run(self, dm):
