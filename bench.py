@@ -506,6 +506,16 @@ def main():
         t_api = (time.perf_counter() - t0) / n_api
         through_api = {"call": "Model.detect(host uint8 ndarray) -> Boxes on the host", "ms_per_image": t_api * 1e3,
                        "windows_per_s": n_loc / t_api, "images": n_api}
+        # ... and the loop the reference's detection script runs over its files (scripts/waldboost-detect.py:64-67),
+        # pipelined: Model.detect_stream keeps three images in flight (upload | scan | read-back and ordering)
+        list(M.detect_stream(imgs[i % len(imgs)] for i in range(12)))
+        torch.cuda.synchronize()
+        n_st = 200
+        t0 = time.perf_counter()
+        n_box = sum(len(bx) for bx in M.detect_stream(imgs[i % len(imgs)] for i in range(n_st)))
+        t_st = (time.perf_counter() - t0) / n_st
+        through_api["stream"] = {"call": "Model.detect_stream(iterable of host uint8 ndarrays) -> Boxes per image, in order",
+                                 "ms_per_image": t_st * 1e3, "windows_per_s": n_loc / t_st, "images": n_st, "lanes": 3}
 
     if rank == 0:
         windows = world * args.steps * B * n_loc

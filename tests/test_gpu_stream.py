@@ -1,0 +1,109 @@
+"""Model.detect_stream: the reference's detection loop (scripts/waldboost-detect.py:64-67 -- model.detect per image)
+pipelined over several engines and streams.  Every image's Boxes must be what Model.detect returns for it (which
+test_gpu_parity pins to the oracle), bit for bit and in the iterable's order; n_loc / n_weak advance the same way."""
+import os
+
+import numpy as np
+import pytest
+
+import waldboost_amd as wb
+from waldboost_amd.synth import synth_image
+from util import GOLDEN, oracle_detect
+
+pytestmark = pytest.mark.gpu
+
+
+def load(name="cfg2_d2_T128.pb"):
+    return wb.load(os.path.join(GOLDEN, "models", name))
+
+
+def mixed_images():
+    """Shapes and dtypes change along the sequence; one image is smaller than the window (no levels)."""
+    out = [synth_image(240, 320, 100 + i) for i in range(7)]
+    out += [synth_image(200, 300, 200 + i).astype(np.float32) for i in range(2)]
+    out += [np.zeros((8, 8), np.uint8)]
+    out += [synth_image(240, 320, 300 + i) for i in range(4)]
+    out += [synth_image(150, 420, 400), synth_image(240, 320, 401), synth_image(150, 420, 402)]
+    return out
+
+
+def same_boxes(a, b):
+    return (np.array_equal(a.get().view(np.uint32), b.get().view(np.uint32))
+            and np.array_equal(a.get_field("scores").view(np.uint32), b.get_field("scores").view(np.uint32)))
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 3])
+def test_stream_equals_detect_per_image(lanes):
+    images = mixed_images()
+    A, B = load(), load()
+    ref = [A.detect(im) for im in images]
+    got = list(B.detect_stream(iter(images), lanes=lanes))
+    assert len(got) == len(ref)
+    assert sum(len(r) for r in ref) > 0
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert same_boxes(g, r), f"image {i}"
+    assert (A.n_loc, A.n_weak) == (B.n_loc, B.n_weak)
+
+
+def test_stream_first_image_against_oracle():
+    M = load()
+    im = synth_image(240, 320, 77)
+    ref = oracle_detect(M, im)
+    got = list(M.detect_stream([im, im, im, im, im]))
+    for g in got:                      # eager call, captured call, replays
+        assert np.array_equal(g.get_field("scores").view(np.uint32), ref["scores"].view(np.uint32))
+        assert np.array_equal(g.get(), ref["boxes"])
+
+
+def test_stream_is_lazy_and_survives_an_early_stop():
+    M = load()
+    taken = []
+
+    def source():
+        for i in range(20):
+            taken.append(i)
+            yield synth_image(240, 320, 500 + i)
+
+    gen = M.detect_stream(source(), lanes=3)
+    first = next(gen)
+    assert len(taken) <= 3                       # at most lanes - 1 images ahead of the one handed out
+    second = next(gen)
+    gen.close()
+    assert len(taken) <= 5
+    N = load()
+    assert same_boxes(first, N.detect(synth_image(240, 320, 500))) and same_boxes(second, N.detect(synth_image(240, 320, 501)))
+    # the lanes are reusable afterwards
+    again = list(M.detect_stream([synth_image(240, 320, 500)]))
+    assert same_boxes(again[0], first)
+
+
+def test_stream_with_a_model_that_grows_between_images():
+    """The cascade is snapshotted per image: stages appended while earlier images are still in flight do not touch them."""
+    M, N = load(), load()
+    ims = [synth_image(240, 320, 600 + i) for i in range(6)]
+    full = list(M.classifier), list(M.theta)
+    k = len(M) // 2
+
+    def cut(model):
+        model.classifier, model.theta = list(full[0][:k]), list(full[1][:k])
+
+    def grow(model):
+        model.classifier, model.theta = list(full[0]), list(full[1])
+
+    cut(M)
+    cut(N)
+
+    def source():
+        for i, im in enumerate(ims):
+            if i == 3:
+                grow(M)
+            yield im
+
+    got = list(M.detect_stream(source(), lanes=3))
+    ref = []
+    for i, im in enumerate(ims):
+        if i == 3:
+            grow(N)
+        ref.append(N.detect(im))
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert same_boxes(g, r), f"image {i}"

@@ -342,3 +342,15 @@ def test_get_regression_target_follows_the_reference():
     get_regression_target(dt, gt)
     want = dt.get() - gt.get()[[0, 1, -1]]
     assert np.array_equal(dt.get_field("regression_target"), want)
+
+
+def test_model_copies_and_pickles_without_its_device_state():
+    """The reference's Model is a plain Python object (model.py:36-67): copy.deepcopy and pickle work on it."""
+    import copy
+    import pickle
+    M = wb.load(os.path.join(GOLDEN, "models", "cfg2_d2_T128.pb"))
+    M._lanes = {"not": "picklable state would live here"}
+    for N in (copy.deepcopy(M), pickle.loads(pickle.dumps(M))):
+        assert len(N) == len(M) and tuple(N.shape) == tuple(M.shape) and "_lanes" not in N.__dict__ and N._device is None
+        for (w, t), (v, u) in zip(M, N):
+            assert t == u and all(np.array_equal(getattr(w, k), getattr(v, k)) for k in ("feature", "threshold", "left", "right", "prediction"))

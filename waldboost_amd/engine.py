@@ -804,6 +804,11 @@ class PyramidEngine:
         wb_det_finish_launch, the two read-back copies -- and its one synchronisation; from the second call with the
         same cascade on it is replayed as ONE hipGraph (one enqueue instead of seven, no gaps between the kernels).
         Returns what fetch_final returns, or None (then: run(dm) has happened, use fetch())."""
+        return self.detect_collect(dm, self.detect_enqueue(dm))
+
+    def detect_enqueue(self, dm):
+        """detect_run up to, not including, its wait: everything is in the current stream when this returns (the image
+        must stay resident until detect_collect, on the same stream, has run).  Returns a token for detect_collect."""
         import torch
         stt = self._casc_state(dm)
         if not self._final_ready():
@@ -824,10 +829,17 @@ class PyramidEngine:
         stt["detect_calls"] = stt.get("detect_calls", 0) + 1
         if g is None:
             self.run(dm)
-            return self.fetch_final(dm, stt)
+            self._final_enqueue(dm, stt)
+            return stt
         self.ensure_clean_keys()
         g.replay()
-        return self.fetch_final(dm, stt, enqueued=True)
+        return stt
+
+    def detect_collect(self, dm, token):
+        """The wait and the read-back that end detect_run, for a token of detect_enqueue."""
+        if token is None:
+            return None
+        return self.fetch_final(dm, token, enqueued=True)
 
     def sorted_detections(self, n=None):
         """Detections ordered by (image, level, r, c) as an int32 [n, 4] tensor of WbDet records."""

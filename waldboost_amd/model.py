@@ -49,6 +49,13 @@ class Model:
         self._content = None
         self.reset()
 
+    def __getstate__(self):
+        """copy / pickle carry the model (the reference's Model is a plain object), not its device-side state."""
+        d = dict(self.__dict__)
+        d["_device"] = d["_content"] = None
+        d.pop("_lanes", None)
+        return d
+
     # ---- statistics (reference model.py:69-89)
     @property
     def eval_cost(self):
@@ -205,7 +212,7 @@ class Model:
         """Results of the scan `stt` of image 0 of `eng`: the dict detect_raw returns; updates n_loc / n_weak.
         fin: what eng.detect_run returned for this scan (False: fetch it here)."""
         m, n, Cc = self.shape
-        T = len(self)
+        T = dm.n_stages                                   # (the cascade that was scanned: detect_stream collects late)
         if fin is False:
             fin = eng.fetch_final(dm, stt)                # ONE host synchronisation: sort keys, boxes, scores, statistics
         if fin is not None:
@@ -250,6 +257,69 @@ class Model:
         d = det.cpu().numpy().view(nat.DET_DTYPE).reshape(-1)
         return dict(boxes=boxes.cpu().numpy(), scores=scores.cpu().numpy(), level=d["level"].copy(),
                     r=d["r"].astype(np.int64), c=d["c"].astype(np.int64), alive=alive, scales=list(eng.plan.scales))
+
+    def detect_stream(self, images, lanes=3):
+        """detect() over an iterable of 2-D images, as a generator of Boxes in the iterable's order -- the loop the
+        reference's detection script runs (scripts/waldboost-detect.py:64-67), pipelined: `lanes` engines, each on its
+        own stream, hold consecutive images, so image i + 1 is uploaded and image i - 1's detections are read back and
+        ordered on the host while image i is scanned (a single detect() call is three quarters upload, waits and host
+        work: DESIGN section 5).  Up to `lanes` - 1 images are taken from the iterable ahead of the one whose Boxes are
+        being yielded.  Same results, same n_loc / n_weak updates as one detect() call per image."""
+        import torch
+        lanes = max(int(lanes), 1)
+        shrink, n_per_oct, smooth, spec = _channels.read_opts(self.channel_opts, allow_callable=True)
+        if spec is None:                      # (a caller's own channel function runs on the host between the GPU steps)
+            for image in images:
+                yield self.detect(image)
+            return
+        m, n, Cc = self.shape
+        assert Cc == spec.n_channels, f"Invalid number of channels. Expected {Cc} given {spec.n_channels}."
+        pool = self.__dict__.setdefault("_lanes", {})        # (H, W, dtype, channel_opts) -> [(engine, stream)]
+        pending = []                                          # [(engine, stream, dm, token)] oldest first
+
+        def finish(item):
+            eng, stream, dm, token = item
+            with torch.cuda.stream(stream):
+                fin = eng.detect_collect(dm, token)
+                res = self._collect(eng, dm, eng._casc_state(dm), False, fin)
+            out = Boxes(res["boxes"])
+            out.set_field("scores", res["scores"])
+            return out
+
+        try:
+            for image in images:
+                _channels._validate_image(image)
+                H, W = image.shape
+                key = (H, W, np.dtype(image.dtype).str, shrink, n_per_oct, smooth, spec.key)
+                group = pool.get(key)
+                if group is None:
+                    if len(pool) >= 2:
+                        pool.pop(next(iter(pool)))
+                    group = pool[key] = []
+                dm = self.device_cascade()
+                # the lane this image takes: one no pending image holds (fewer than `lanes` images are pending here)
+                busy = {id(it[0]) for it in pending}
+                lane = next((ln for ln in group if id(ln[0]) not in busy), None)
+                if lane is None:
+                    lane = (_engine.PyramidEngine(H, W, image.dtype, shrink, n_per_oct, smooth, 1, channels=spec),
+                            torch.cuda.Stream())
+                    group.append(lane)
+                eng, stream = lane
+                if eng.plan.n_levels == 0:
+                    while pending:
+                        yield finish(pending.pop(0))
+                    yield self.detect(image)
+                    continue
+                with torch.cuda.stream(stream):
+                    eng.load_images(image)
+                    pending.append((eng, stream, dm, eng.detect_enqueue(dm)))
+                if len(pending) >= lanes:
+                    yield finish(pending.pop(0))
+            while pending:
+                yield finish(pending.pop(0))
+        finally:
+            for eng, stream, _, _ in pending:                 # (the consumer stopped early: let the lanes drain)
+                stream.synchronize()
 
     def detect_batch(self, images):
         """detect() on a batch: `images` is [B,H,W] (ndarray or device tensor) of one shape and dtype;
