@@ -507,15 +507,19 @@ def main():
         through_api = {"call": "Model.detect(host uint8 ndarray) -> Boxes on the host", "ms_per_image": t_api * 1e3,
                        "windows_per_s": n_loc / t_api, "images": n_api}
         # ... and the loop the reference's detection script runs over its files (scripts/waldboost-detect.py:64-67),
-        # pipelined: Model.detect_stream keeps three images in flight (upload | scan | read-back and ordering)
-        list(M.detect_stream(imgs[i % len(imgs)] for i in range(12)))
-        torch.cuda.synchronize()
-        n_st = 200
-        t0 = time.perf_counter()
-        n_box = sum(len(bx) for bx in M.detect_stream(imgs[i % len(imgs)] for i in range(n_st)))
-        t_st = (time.perf_counter() - t0) / n_st
-        through_api["stream"] = {"call": "Model.detect_stream(iterable of host uint8 ndarrays) -> Boxes per image, in order",
-                                 "ms_per_image": t_st * 1e3, "windows_per_s": n_loc / t_st, "images": n_st, "lanes": 3}
+        # pipelined: Model.detect_stream keeps three lanes in flight (upload | scan | read-back and ordering), one image
+        # or a batch of 16 per lane
+        def stream_rate(batch, n_st):
+            gen = lambda k: (imgs[i % len(imgs)] for i in range(k))
+            list(M.detect_stream(gen(3 * 3 * batch), batch=batch))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_box = sum(len(bx) for bx in M.detect_stream(gen(n_st), batch=batch))
+            t_st = (time.perf_counter() - t0) / n_st
+            return {"ms_per_image": t_st * 1e3, "windows_per_s": n_loc / t_st, "images": n_st, "lanes": 3, "batch": batch,
+                    "boxes_per_image": n_box / n_st}
+        through_api["stream"] = dict(stream_rate(1, 200), call="Model.detect_stream(iterable of host uint8 ndarrays) -> Boxes per image, in order")
+        through_api["stream_batch16"] = dict(stream_rate(16, 480), call="Model.detect_stream(..., batch=16)")
 
     if rank == 0:
         windows = world * args.steps * B * n_loc

@@ -32,9 +32,9 @@ def same_boxes(a, b):
             and np.array_equal(a.get_field("scores").view(np.uint32), b.get_field("scores").view(np.uint32)))
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 3])
+@pytest.mark.parametrize("lanes", [1, 2, 3, 5])
 def test_stream_equals_detect_per_image(lanes):
-    images = mixed_images()
+    images = mixed_images() * 2            # (the second pass finds every lane's graph captured)
     A, B = load(), load()
     ref = [A.detect(im) for im in images]
     got = list(B.detect_stream(iter(images), lanes=lanes))
@@ -105,5 +105,66 @@ def test_stream_with_a_model_that_grows_between_images():
         if i == 3:
             grow(N)
         ref.append(N.detect(im))
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert same_boxes(g, r), f"image {i}"
+
+
+def test_stream_hands_an_upload_error_to_the_consumer():
+    M = load()
+    good = [synth_image(240, 320, 700 + i) for i in range(8)]
+    bad = np.zeros((240, 320), np.complex64)
+    gen = M.detect_stream(good + [bad] + good[:2], lanes=3)
+    with pytest.raises((TypeError, NotImplementedError, ValueError)):
+        list(gen)
+    # ... and a later stream on the same lanes is unharmed
+    N = load()
+    assert same_boxes(list(M.detect_stream(good[:1]))[0], N.detect(good[0]))
+
+
+def test_stream_grows_a_lane_whose_detection_buffer_overflows():
+    from waldboost_amd import _native as nat
+    M, N = load(), load()
+    ims = [synth_image(240, 320, 800 + i) for i in range(9)]
+    ref = [N.detect(im) for im in ims]
+    assert max(len(r) for r in ref) > 16
+    list(M.detect_stream(ims, lanes=3))                     # lanes built, graphs captured
+    for group in M._lanes.values():
+        for eng, _ in group:
+            eng.det_capacity = 16 * nat.WB_DET_SHARDS       # far too small: every shard overflows
+            eng._alloc_det()
+    got = list(M.detect_stream(ims, lanes=3))
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert same_boxes(g, r), f"image {i}"
+
+
+@pytest.mark.parametrize("lanes,batch", [(3, 4), (2, 3), (1, 2), (3, 16)])
+@pytest.mark.parametrize("device_post", [False, True])
+def test_stream_in_batches_equals_detect_per_image(lanes, batch, device_post, monkeypatch):
+    """Batches fill image by image; a shape change, the tiny image and the end of the sequence send partly filled ones
+    (whose stale slots must not show).  device_post: ordering and boxes on the device (as with many detections)."""
+    import waldboost_amd.model as wm
+    if device_post:
+        monkeypatch.setattr(wm, "_HOST_POST_BATCH", 0)
+    images = mixed_images() * 2
+    A, B = load(), load()
+    ref = [A.detect(im) for im in images]
+    got = list(B.detect_stream(iter(images), lanes=lanes, batch=batch))
+    assert len(got) == len(ref)
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert same_boxes(g, r), f"image {i}"
+    assert (A.n_loc, A.n_weak) == (B.n_loc, B.n_weak)
+
+
+def test_stream_in_batches_grows_an_overflowing_detection_buffer():
+    from waldboost_amd import _native as nat
+    M, N = load(), load()
+    ims = [synth_image(240, 320, 900 + i) for i in range(10)]
+    ref = [N.detect(im) for im in ims]
+    list(M.detect_stream(ims, lanes=2, batch=4))
+    for group in M._lanes.values():
+        for eng, _ in group:
+            eng.det_capacity = 16 * nat.WB_DET_SHARDS
+            eng._alloc_det()
+    got = list(M.detect_stream(ims, lanes=2, batch=4))
     for i, (g, r) in enumerate(zip(got, ref)):
         assert same_boxes(g, r), f"image {i}"

@@ -457,6 +457,21 @@ class PyramidEngine:
             t = torch.from_numpy(np.ascontiguousarray(images))
         self.img.copy_(t, non_blocking=True)
 
+    def load_slot(self, b, image):
+        """One 2-D host image into slot b of the batch (Model.detect_stream fills a batch image by image)."""
+        import torch
+        self.epoch += 1
+        if not isinstance(image, np.ndarray) or image.dtype != self.dtype:
+            raise TypeError(f"engine built for {self.dtype} images, got {getattr(image, 'dtype', type(image))}")
+        if tuple(image.shape) != (self.plan.H, self.plan.W):
+            raise ValueError(f"expected an image of shape {(self.plan.H, self.plan.W)}, got {tuple(image.shape)}")
+        if image.dtype != self.store_dtype:
+            if image.dtype.itemsize == 8 and image.dtype.kind in "iu" and image.size:
+                if max(abs(int(image.max())), abs(int(image.min()))) >= 1 << 51:
+                    raise NotImplementedError("64 bit integer images are supported for values below 2**51 (they are held as float64)")
+            image = image.astype(self.store_dtype)
+        self.img[b].copy_(torch.from_numpy(np.ascontiguousarray(image)), non_blocking=True)
+
     # ------------------------------------------------------------------ launches
     def launch_octaves(self, zero=None):
         """zero: a tensor view of accumulator words the launch's first workgroup resets (see run)."""
@@ -700,12 +715,14 @@ class PyramidEngine:
                   "wb_det_pack_launch")
         return self.packed
 
-    def fetch(self, dm, stt):
+    def fetch(self, dm, stt, limit=None):
         """Everything the host needs from the last scan in ONE synchronisation: the shard contents packed on
         the device (wb_det_pack_launch), then asynchronous copies of the header + first records and of
         alive[B, L, T] into page-locked memory, one event wait.  Grows the buffer and scans again if a shard
         overflowed; a second copy only when there are more than _FETCH_ROWS detections.
-        Returns (records int32 [n, 4] in shard order, alive int64 [B, L, T])."""
+        Returns (records int32 [n, 4] in shard order, alive int64 [B, L, T]).
+        limit: with more than `limit` detections the records stay on the device (self.packed[1:1 + n]; the caller orders
+        them there) and their count is returned in place of the array."""
         import torch
         T = dm.n_stages
         while True:
@@ -726,10 +743,12 @@ class PyramidEngine:
             self.det_capacity = (int(worst * 1.5) + 16) * nat.WB_DET_SHARDS
             self._alloc_det()
             stt = self.run_cascade(dm, ranks=stt.get("ranks", False))
+        alive = self._h_alive.numpy()[:, :, :T].astype(np.int64)
+        if limit is not None and total > limit:
+            return total, alive
         recs = self._h_packed[1:1 + min(total, rows - 1)].numpy().copy()
         if total > rows - 1:
             recs = np.concatenate([recs, self.packed[rows:1 + total].cpu().numpy()])
-        alive = self._h_alive.numpy()[:, :, :T].astype(np.int64)
         return recs, alive
 
     def _final_ready(self):
@@ -770,14 +789,16 @@ class PyramidEngine:
         stt["h_final"].copy_(stt["final"], non_blocking=True)
         stt["h_alive"].copy_(stt["alive"], non_blocking=True)
 
-    def fetch_final(self, dm, stt, enqueued=False):
+    def fetch_final(self, dm, stt, enqueued=False, stream=None):
         """fetch() for Model.detect on ONE image: wb_det_finish_launch leaves sort keys, boxes and scores of all
         valid records behind one header; they come back with ONE copy and ONE event wait together with alive[B, L, T].
         Returns (keys uint64 [n] (level << 54 | r << 40 | c << 26 | position), boxes float32 [rows, 4], scores
         float32 [rows], alive int64 [B, L, T]) -- keys unsorted, boxes / scores indexed by a key's position -- or
         None when this form does not apply (a batch, a pyramid beyond the key's bit fields, more than _FETCH_ROWS
         detections): use fetch() then.  Grows the detection buffer and scans again if a shard overflowed.
-        enqueued: the launch and the copies are already in the stream (detect_run's graph replay)."""
+        enqueued: the launch and the copies are already in the stream (detect_run's graph replay).
+        stream: that stream, when it is not the current one -- then only the wait happens here, and False is returned
+        if more than a wait is needed (the caller comes back on that stream)."""
         if not self._final_ready():
             return None
         P, T = self._FETCH_ROWS, dm.n_stages
@@ -785,12 +806,17 @@ class PyramidEngine:
             if not enqueued:
                 self._final_enqueue(dm, stt)
             enqueued = False
-            self._fetch_ev.record()
+            if stream is None:
+                self._fetch_ev.record()
+            else:
+                self._fetch_ev.record(stream)
             self._fetch_ev.synchronize()
             hdr, keys, boxes, scores = stt["h_final_views"]
             total, worst = int(hdr[0]), int(hdr[1])
             if worst <= self.detb.cap:
                 break
+            if stream is not None:
+                return False
             self.det_capacity = (int(worst * 1.5) + 16) * nat.WB_DET_SHARDS
             self._alloc_det()
             stt = self.run_cascade(dm, ranks=stt.get("ranks", False))
@@ -835,11 +861,36 @@ class PyramidEngine:
         g.replay()
         return stt
 
-    def detect_collect(self, dm, token):
-        """The wait and the read-back that end detect_run, for a token of detect_enqueue."""
-        if token is None:
-            return None
-        return self.fetch_final(dm, token, enqueued=True)
+    def batch_enqueue(self, dm):
+        """The step -- octaves, channels, cascade -- over the resident batch, without a wait: eager on an engine's first
+        call, a replayed hipGraph afterwards (captured again when the engine re-allocated a buffer the graph addresses).
+        Returns the scan state fetch() takes."""
+        stt = self._casc_state(dm)
+        step = stt.get("step")
+        if step is not None and step.generation != self.generation:
+            step = None
+        if step is None and stt.get("batch_calls", 0) >= 1 and not _NO_DETECT_GRAPH:
+            dm.note_scan(nat.WB_DTYPE_RANK8 if self.ranks_for(dm) else self.spec.wb_dtype, force=True)
+            step = stt["step"] = self.capture(dm)
+        stt["batch_calls"] = stt.get("batch_calls", 0) + 1
+        if step is None:
+            self.run(dm)
+        else:
+            step.replay()
+        return stt
+
+    def detect_collect(self, dm, token, stream=None):
+        """The wait and the read-back that end detect_run, for a token of detect_enqueue.
+        stream: the stream detect_enqueue ran on, when that is not the current one."""
+        import torch
+        if stream is None:
+            return None if token is None else self.fetch_final(dm, token, enqueued=True)
+        if token is not None:
+            fin = self.fetch_final(dm, token, enqueued=True, stream=stream)
+            if fin is not False:
+                return fin
+        with torch.cuda.stream(stream):                       # (the rare ways out: launches and copies of their own)
+            return None if token is None else self.fetch_final(dm, token, enqueued=False)
 
     def sorted_detections(self, n=None):
         """Detections ordered by (image, level, r, c) as an int32 [n, 4] tensor of WbDet records."""
