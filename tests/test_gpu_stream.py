@@ -168,3 +168,19 @@ def test_stream_in_batches_grows_an_overflowing_detection_buffer():
     got = list(M.detect_stream(ims, lanes=2, batch=4))
     for i, (g, r) in enumerate(zip(got, ref)):
         assert same_boxes(g, r), f"image {i}"
+
+
+def test_detect_on_images_through_the_stream():
+    """testing.detect_on_images (reference testing.py:127-132) with lanes / batch: the same tuples as its plain loop."""
+    from waldboost_amd.testing import detect_on_images
+    from waldboost_amd.boxes import Boxes
+    M, N = load(), load()
+    ims = mixed_images()
+    dicts = [{"image": im, "groundtruth_boxes": Boxes(np.array([[1.0, 2.0, 30.0 + i, 40.0]]))} if i % 2 else {"image": im}
+             for i, im in enumerate(ims)]
+    ref = list(detect_on_images(dicts, N))
+    got = list(detect_on_images(iter(dicts), M, lanes=3, batch=4))
+    assert len(ref) == len(got) == len(ims)
+    for (g0, d0, s0), (g1, d1, s1) in zip(ref, got):
+        assert s0 == s1 and np.array_equal(g0.get(), g1.get())
+        assert same_boxes(d0, d1) and np.array_equal(d0.get_field("label"), d1.get_field("label"))
