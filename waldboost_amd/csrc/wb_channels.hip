@@ -289,9 +289,13 @@ template <int S_, int TU_, int TV_, bool SMOOTH_, int NT_ = 256> struct TileGeom
     // (shrink 2: 74 rows x 256 bytes instead of 80 x 236 -- the most down-scaled level of an octave of 8, zoom step
     // 1.834, needs 72 rows of 254 bytes and took the direct path before)
     // (32-row tiles: 70 resized rows at zoom step 1.834 tap 130 source rows)
+    // (shrink 4, an extension: 42 x 138 resized pixels per 8 x 32 outputs tap up to 86 source rows of 278 bytes -- five
+    // times the shrunk tile; the patch gets its own size, three workgroups per CU.  Sized after the shrunk tile, as until
+    // round 3, no shrink-4 tile was ever staged: four byte gathers per resized pixel straight from memory)
     static constexpr int PROWS = S == 2 ? (TU == 16 ? 74 : 2 * RH - 8) : 2 * RH + 4;
-    static constexpr int PPITCH = (S == 2 && TU != 16) ? 256 : ((SU * SV * 16) / PROWS) & ~3;
-    static_assert(PROWS * PPITCH <= SU * SV * 16, "the source patch shares the shrunk tile's memory");
+    static constexpr int PPITCH = S == 4 ? 2 * RW + 12 : (S == 2 && TU != 16) ? 256 : ((SU * SV * 16) / PROWS) & ~3;
+    static_assert(S == 4 || PROWS * PPITCH <= SU * SV * 16, "the source patch shares the shrunk tile's memory");
+    static_assert(PPITCH % 4 == 0, "patch rows are written as dwords");
     static constexpr int SH_BYTES = SU * SV * 16;
     static constexpr int PATCH_BYTES = PROWS * PPITCH;
 };
@@ -673,7 +677,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
 // allocator may trade that occupancy for a few more registers -- measured: 138 VGPRs, 3 waves per SIMD, +17 % time)
 // (NT threads per workgroup: 256 for the 16 x 64 tile, 512 for the 32 x 64 tile -- the same 4 waves per SIMD either way)
 template <typename T, int S, int TU, int TV, bool SMOOTH, bool FAST, int NT>
-__global__ __launch_bounds__(NT, sizeof(T) == 8 || S == 4 ? 1 : 4) void channels_kernel(ChanArgs a) {
+__global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ? 3 : 1) : 4) void channels_kernel(ChanArgs a) {
     using G = TileGeom<S, TU, TV, SMOOTH, NT>;
     constexpr int HS = G::HS, SU = G::SU, SV = G::SV, RH = G::RH, RW = G::RW, P = G::P;
     constexpr int PATCH_BYTES = sizeof(T) == 1 ? G::PATCH_BYTES : 0;
