@@ -679,7 +679,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
 template <typename T, int S, int TU, int TV, bool SMOOTH, bool FAST, int NT>
 __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ? 3 : 1) : 4) void channels_kernel(ChanArgs a) {
     using G = TileGeom<S, TU, TV, SMOOTH, NT>;
-    constexpr int HS = G::HS, SU = G::SU, SV = G::SV, RH = G::RH, RW = G::RW, P = G::P;
+    constexpr int HS = G::HS, SV = G::SV, RH = G::RH, RW = G::RW, P = G::P;
     constexpr int PATCH_BYTES = sizeof(T) == 1 ? G::PATCH_BYTES : 0;
     constexpr int UNI_BYTES = G::SH_BYTES > PATCH_BYTES ? G::SH_BYTES : PATCH_BYTES;
     constexpr int R_FLOATS = RH * RW > WB_BIN_LUT_BYTES / 4 ? RH * RW : WB_BIN_LUT_BYTES / 4;   // (R later holds the rank tables)
