@@ -492,6 +492,45 @@ def test_multi_model_detect_shares_one_pyramid():
         wb.detect(img, *models, response_scale=[1.0])
 
 
+def compose_multi(models, refs, rs):
+    """The reference's nested loops (__init__.py:118-128) over per-model results: level-major, then model."""
+    boxes, scores, labels = [np.empty((0, 4), np.float32)], [np.empty(0, np.float32)], [np.empty(0, np.int64)]
+    for lv in range(refs[0]["alive"].shape[0]):
+        for k, r in enumerate(refs):
+            sel = r["level"] == lv
+            boxes.append(r["boxes"][sel])
+            scores.append(r["scores"][sel] * np.float32(rs[k]))
+            labels.append(np.full(int(sel.sum()), k, np.int64))
+    return np.concatenate(boxes), np.concatenate(scores), np.concatenate(labels)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_multi_model_detect_repeated_calls_replay_one_graph(dtype):
+    """waldboost.detect again and again with the same models (eager call, captured call, replays), other users of the
+    same engine in between (Model.detect of one of the models and of a third one: they leave their own ranks, dirty
+    octave keys and their own scan states behind): every call equals the composition of the oracle's per-model results."""
+    models = [random_model(700 + k, 24 + 8 * k, 2) for k in range(2)]
+    other = random_model(777, 16, 1)
+    rs = [1.0, 0.75]
+    total = 0
+    for i in range(6):
+        img = synth_image(260, 380, 880 + i).astype(dtype)
+        if i == 3:
+            models[1].detect(img)
+            other.detect(synth_image(260, 380, 3).astype(dtype))
+        before = [(M.n_loc, M.n_weak) for M in models]
+        out = wb.detect(img, *models, response_scale=rs)
+        refs = [oracle_detect(M, img) for M in models]
+        boxes, scores, labels = compose_multi(models, refs, rs)
+        assert np.array_equal(out.get(), boxes), f"call {i}"
+        assert np.array_equal(bits(out.get_field("scores")), bits(scores)), f"call {i}"
+        assert np.array_equal(out.get_field("label"), labels), f"call {i}"
+        for M, r, (l0, w0) in zip(models, refs, before):
+            assert (M.n_loc - l0, M.n_weak - w0) == (r["n_loc"], r["n_weak"])
+        total += len(out)
+    assert total > 0
+
+
 # ------------------------------------------------------------------------------ batches / configs
 def test_detect_batch_equals_per_image_detect():
     imgs = np.stack([synth_image(210, 290, 600 + b) for b in range(5)])

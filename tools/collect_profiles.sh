@@ -22,6 +22,8 @@ WB_CASC_JIT=0 timeout -k 10 300 python3 bench.py --batch 64 --steps 10 --warmup 
 timeout -k 10 300 python3 bench.py --gpus 2 --backend gloo --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_2ranks_gloo_selflaunch.json 2>> $O/bench_default.err || exit 1
 timeout -k 10 300 python3 tools/bench_cfg5.py > $O/bench_cfg5.txt 2>> $O/bench_default.err || exit 1
 timeout -k 10 300 python3 tools/bench_next_rows.py > $O/bench_next_rows.txt 2>> $O/bench_default.err || exit 1
+# (the two-model call once more with a read-back that holds the synthetic image's 4000+ detections per model)
+WB_FETCH_ROWS=8192 timeout -k 10 300 python3 tools/bench_next_rows.py 2>> $O/bench_default.err | grep "waldboost.detect" >> $O/bench_next_rows.txt || exit 1
 timeout -k 10 300 python3 tools/detect_breakdown.py > $O/model_detect_host_timeline.txt 2>> $O/bench_default.err || exit 1
 echo "bench lines done"
 fi

@@ -52,13 +52,20 @@ def detect(image, *models, channel_opts=None, response_scale=None):
     if spec.key == "grad_hist" and not _engine._NO_RANKS and all(m.shape[2] == spec.n_channels for m in models):
         group = _engine.rank_group([m.device_cascade() for m in models])
     views = group.views if group is not None else [None] * len(models)
-    if group is not None:
-        eng.run_channels(rank_dm=group.views[0], floats=False)
+    dms = [v if v is not None else m.device_cascade() for m, v in zip(models, views)]
+    for m in models:
+        assert m.shape[2] == eng.spec.n_channels, f"Invalid number of channels. Expected {m.shape[2]} given {eng.spec.n_channels}."
+    # the whole sequence -- octaves, the pyramid, per model its scan, boxes and read-back -- as ONE hipGraph replay with
+    # ONE wait from the second call on (like Model.detect); model by model where that form does not apply
+    fins = eng.detect_multi_run(dms, ranks=group is not None)
+    if fins is not None:
+        res = [m._collect(eng, d, eng._casc_state(d), True, fin) for m, d, fin in zip(models, dms, fins)]
     else:
-        eng.run_channels()
-    # (one wait per model: enqueueing every model's scan and read-back first and waiting once was measured SLOWER --
-    # 0.80 against 0.69 ms per call for two 128-stage models at 1080p)
-    res = [m.scan_engine(eng, view=v) for m, v in zip(models, views)]
+        if group is not None:
+            eng.run_channels(rank_dm=group.views[0], floats=False)
+        else:
+            eng.run_channels()
+        res = [m.scan_engine(eng, view=v) for m, v in zip(models, views)]
     # level-major, then model, then row-major: every model's result is ordered by (level, r, c) already, so ONE stable sort
     # by (level, model) gives the reference's nested-loop order (a Python loop over levels x models building Boxes was
     # 0.8 ms of a 1.1 ms call)

@@ -310,7 +310,9 @@ class CapturedStep:
 
 
 class PyramidEngine:
-    _FETCH_ROWS = 4096            # detection records read back with the first copy of fetch()
+    # detection records read back with the first copy of fetch() / the one copy of fetch_final() (28 bytes each; the
+    # copies inside a captured graph have this fixed size).  WB_FETCH_ROWS: diagnostic override
+    _FETCH_ROWS = int(os.environ.get("WB_FETCH_ROWS", "4096"))
 
     def __init__(self, H, W, dtype, shrink, n_per_oct, smooth, batch=1, exact_single=False, det_capacity=1 << 16,
                  channels=None):
@@ -396,6 +398,7 @@ class PyramidEngine:
         if getattr(self, "detb", None) is not None:
             self.detb.counts = self._counts
         self._casc = {}
+        self._multi = {}              # detect_multi_run's captured sequences, by cascade list
 
     def _alive_view(self, T1):
         L = max(self.plan.n_levels, 1)
@@ -878,6 +881,61 @@ class PyramidEngine:
         else:
             step.replay()
         return stt
+
+    def detect_multi_run(self, dms, ranks):
+        """waldboost.detect's whole device sequence for the resident image -- octaves, ONE channel pyramid (as ranks of
+        dms[0]'s rank tables -- a rank group's union tables -- or as float32 channels), then per cascade of `dms` its
+        scan, wb_det_finish_launch and the read-back copies -- with ONE wait at its end; from the second call with the
+        same cascades on it is one hipGraph replay.  Returns [what fetch_final returns, per cascade], or None when that
+        form does not apply (more cascades than an engine keeps states for, a pyramid beyond the sort key's fields, an
+        overflowing detection buffer, more detections than one read-back holds): the caller then scans model by model."""
+        import torch
+        if not self._final_ready() or not 0 < len(dms) <= 4 or len({id(d) for d in dms}) != len(dms):
+            return None
+        key = tuple(id(d) for d in dms) + (bool(ranks),)
+        stts = [self._casc_state(d) for d in dms]            # (may grow the control block: before the generation is read)
+        if any(self._casc.get(id(d)) is not t for d, t in zip(dms, stts)):
+            return None
+        st = self._multi.get(key)
+        if st is None or st["generation"] != self.generation or any(a is not b for a, b in zip(st["stts"], stts)):
+            if len(self._multi) >= 2:
+                self._multi.pop(next(iter(self._multi)))
+            st = self._multi[key] = dict(generation=self.generation, stts=stts, dms=list(dms), calls=0, graph=None, skip=0)
+        if st["skip"] > 0:                                    # (its results did not fit lately: do not scan twice per call)
+            st["skip"] -= 1
+            return None
+
+        def enqueue():
+            self.run_channels(rank_dm=dms[0] if ranks else None, floats=not ranks)
+            for d in dms:
+                self._final_enqueue(d, self.run_cascade(d, ranks=ranks))
+
+        if st["graph"] is None and st["calls"] >= 1 and not _NO_DETECT_GRAPH:
+            for d in dms:
+                d.note_scan(nat.WB_DTYPE_RANK8 if ranks else self.spec.wb_dtype, force=True)
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                enqueue()
+            st["graph"] = g
+        st["calls"] += 1
+        if st["graph"] is None:
+            enqueue()
+        else:
+            self._mm_clean = False                            # (the replay's octave launch leaves its keys behind)
+            st["graph"].replay()
+            self.rank_owner = dms[0].rank_key if ranks else None
+        self._fetch_ev.record()
+        self._fetch_ev.synchronize()
+        out = []
+        for d, stt in zip(dms, stts):
+            hdr, keys, boxes, scores = stt["h_final_views"]
+            total, worst = int(hdr[0]), int(hdr[1])
+            if worst > self.detb.cap or total > self._FETCH_ROWS:
+                st["skip"] = 16
+                return None
+            out.append((keys[:total], boxes, scores, stt["h_alive"].numpy()[:, :, :d.n_stages].astype(np.int64)))
+        return out
 
     def detect_collect(self, dm, token, stream=None):
         """The wait and the read-back that end detect_run, for a token of detect_enqueue.
