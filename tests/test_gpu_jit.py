@@ -113,3 +113,14 @@ def test_auto_specialisation_after_a_few_scans_and_models_it_cannot_take():
     assert_same(deep.detect_raw(img), oracle_detect(deep, img))
     # float32 channel tiles have no specialised kernel
     assert dm.specialize(nat.WB_DTYPE_F32) is False
+
+
+@pytest.mark.parametrize("seed", [3, 17, 26, 41, 58, 63])
+def test_random_configurations_with_the_cascade_specialised_on_its_first_scan(seed, monkeypatch):
+    """The randomised end-to-end test (test_gpu_fuzz) with every eligible cascade compiled before its first scan
+    (tools/fuzz_more.py with WB_CASC_JIT_AFTER=1 runs further seeds the same way)."""
+    import test_gpu_fuzz as F
+    from waldboost_amd import engine as E
+    monkeypatch.setattr(E, "_JIT_AFTER", 1)
+    monkeypatch.setattr(E, "_JIT_AUTO", True)
+    F.test_random_configuration(seed)

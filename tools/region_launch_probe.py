@@ -38,7 +38,22 @@ for j, e in enumerate(engines):
         for _ in range(K // P - 1):
             e.run(dm)
     tail_graphs.append(g)
+# (e) ONE graph: the four streams' chains as parallel branches (fork from / join into the capture stream)
+fork_graph = torch.cuda.CUDAGraph()
+cap = torch.cuda.Stream()
+with torch.cuda.graph(fork_graph, stream=cap):
+    for st in lanes:
+        st.wait_stream(cap)
+    for j, e in enumerate(engines):
+        with torch.cuda.stream(lanes[j]):
+            for _ in range(K // P):
+                e.run(dm)
+    for st in lanes:
+        cap.wait_stream(st)
 torch.cuda.synchronize()
+
+def region_e():
+    fork_graph.replay()
 
 def region_d():
     for j in range(P):
@@ -81,6 +96,8 @@ timeit(region_a, "(a) one replay per step, round-robin")
 timeit(region_b, "(b) one graph per stream, one host thread")
 timeit(region_c, "(c) one graph per stream, one host thread each")
 timeit(region_d, "(d) per stream: a 1-step graph, then a 4-step graph")
+timeit(region_e, "(e) one graph, four parallel branches")
 timeit(region_b, "(b) again")
+timeit(region_e, "(e) again")
 timeit(region_d, "(d) again")
 stop = True; start.wait()
