@@ -193,6 +193,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
+    # stdout carries rank 0's ONE JSON line and nothing else: whatever a library writes to file descriptor 1 meanwhile
+    # (gloo prints a connection banner there) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
     if args.dry_launch:
         import torch
         import torch.distributed as dist
@@ -202,9 +211,9 @@ def main():
         seen = torch.zeros(world, dtype=torch.int64)
         dist.all_gather_into_tensor(seen, torch.tensor([rank * 10 + local_rank], dtype=torch.int64))
         if rank == 0:
-            print(json.dumps({"dry_launch": True, "n_gpus": args.gpus, "world_size_reported": dist.get_world_size(),
-                              "ranks": [int(x) // 10 for x in seen], "local_ranks": [int(x) % 10 for x in seen],
-                              "backend": args.backend, "steps": args.steps, "warmup": args.warmup, "batch_per_gpu": args.batch}))
+            emit({"dry_launch": True, "n_gpus": args.gpus, "world_size_reported": dist.get_world_size(),
+                  "ranks": [int(x) // 10 for x in seen], "local_ranks": [int(x) % 10 for x in seen],
+                  "backend": args.backend, "steps": args.steps, "warmup": args.warmup, "batch_per_gpu": args.batch})
         dist.destroy_process_group()
         return
 
@@ -549,7 +558,7 @@ def main():
             "kernels": kern, "parity": parity, "ranks": per_rank, "through_api": through_api,
             "roofline": roof, "issue_bound": issue_bound(roof, B, args.channels), "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        emit(out)
     if coll:
         dist.destroy_process_group()
 

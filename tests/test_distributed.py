@@ -241,9 +241,9 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     import json
     r = _run_bench("--gpus", "2", "--dry-launch", "--steps", "2", "--warmup", "1")
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    out = lines[0]
+    # stdout is that line and nothing else (gloo's connection banner, which it writes to stdout, goes to stderr)
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout
+    out = json.loads(r.stdout)
     assert out["dry_launch"] and out["n_gpus"] == 2 and out["world_size_reported"] == 2
     assert out["ranks"] == [0, 1] and out["local_ranks"] == [0, 1] and out["steps"] == 2
 

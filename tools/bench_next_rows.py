@@ -87,7 +87,7 @@ for label, no_ranks in (("float32 pyramid", True), ("rank pyramid (union table)"
         out = wb.detect(img1, M1, M2)
     dt = (time.perf_counter() - t0) / n
     eng = E.get_engine(1080, 1920, np.uint8, 2, 8, 1, 1)
-    one = any(st["graph"] is not None and st["skip"] == 0 for st in eng._multi.values())
+    one = any(st["fails"] == 0 and st["calls"] > 0 for st in eng._multi.values())
     eng._multi.clear()
     print(f"waldboost.detect, 2 models x 128 stages, 1080p, {label:28s}: {dt * 1e3:7.3f} ms per call, {len(out)} boxes "
           f"({'one graph replay, one wait' if one else 'model by model: more than ' + str(eng._FETCH_ROWS) + ' detections of one model -- one read-back does not hold them'}"

@@ -900,7 +900,7 @@ class PyramidEngine:
         if st is None or st["generation"] != self.generation or any(a is not b for a, b in zip(st["stts"], stts)):
             if len(self._multi) >= 2:
                 self._multi.pop(next(iter(self._multi)))
-            st = self._multi[key] = dict(generation=self.generation, stts=stts, dms=list(dms), calls=0, graph=None, skip=0)
+            st = self._multi[key] = dict(generation=self.generation, stts=stts, dms=list(dms), calls=0, graph=None, skip=0, fails=0)
         if st["skip"] > 0:                                    # (its results did not fit lately: do not scan twice per call)
             st["skip"] -= 1
             return None
@@ -932,9 +932,11 @@ class PyramidEngine:
             hdr, keys, boxes, scores = stt["h_final_views"]
             total, worst = int(hdr[0]), int(hdr[1])
             if worst > self.detb.cap or total > self._FETCH_ROWS:
-                st["skip"] = 16
+                st["fails"] += 1                              # (tried again after 16, 32, 64 ... calls)
+                st["skip"] = min(8 << st["fails"], 4096)
                 return None
             out.append((keys[:total], boxes, scores, stt["h_alive"].numpy()[:, :, :d.n_stages].astype(np.int64)))
+        st["fails"] = 0
         return out
 
     def detect_collect(self, dm, token, stream=None):
