@@ -910,7 +910,8 @@ class PyramidEngine:
             for d in dms:
                 self._final_enqueue(d, self.run_cascade(d, ranks=ranks))
 
-        if st["graph"] is None and st["calls"] >= 1 and not _NO_DETECT_GRAPH:
+        if st["graph"] is None and st["calls"] >= 1 and st["fails"] == 0 and not _NO_DETECT_GRAPH:
+            # (captured after an eager call whose results fitted: a sequence that keeps missing is not worth a capture)
             for d in dms:
                 d.note_scan(nat.WB_DTYPE_RANK8 if ranks else self.spec.wb_dtype, force=True)
             g = torch.cuda.CUDAGraph()
