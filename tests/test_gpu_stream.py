@@ -184,3 +184,24 @@ def test_detect_on_images_through_the_stream():
     for (g0, d0, s0), (g1, d1, s1) in zip(ref, got):
         assert s0 == s1 and np.array_equal(g0.get(), g1.get())
         assert same_boxes(d0, d1) and np.array_equal(d0.get_field("label"), d1.get_field("label"))
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_stream_with_more_detections_than_one_read_back_holds(batch, monkeypatch):
+    """Model.detect's one-copy read-back holds _FETCH_ROWS detections; beyond that the records are fetched with further
+    copies (and, in batches, ordered on the device) -- shrunk to 64 rows here, so that ordinary images exceed it."""
+    from waldboost_amd import engine as E
+    E._ENGINES.clear()                                  # (cached engines hold read-back buffers of the usual size)
+    monkeypatch.setattr(E.PyramidEngine, "_FETCH_ROWS", 64)
+    try:
+        M, N = load(), load()
+        ims = [synth_image(240, 320, 950 + i) for i in range(7)]
+        ref = [N.detect(im) for im in ims]
+        assert max(len(r) for r in ref) > 64
+        got = list(M.detect_stream(ims, lanes=3, batch=batch))
+        for i, (g, r) in enumerate(zip(got, ref)):
+            assert same_boxes(g, r), f"image {i}"
+        o = oracle_detect(N, ims[0])
+        assert np.array_equal(ref[0].get(), o["boxes"]) and np.array_equal(ref[0].get_field("scores").view(np.uint32), o["scores"].view(np.uint32))
+    finally:
+        E._ENGINES.clear()

@@ -288,7 +288,11 @@ class Model:
             eng, stream, dm, token, count = item
             if K == 1:
                 fin = eng.detect_collect(dm, token, stream)
-                res = self._collect(eng, dm, eng._casc_state(dm), False, fin)
+                if fin is None:                               # (more detections than the one read-back holds: further copies)
+                    with torch.cuda.stream(stream):
+                        res = self._collect(eng, dm, eng._casc_state(dm), False, None)
+                else:
+                    res = self._collect(eng, dm, eng._casc_state(dm), False, fin)
                 out = Boxes(res["boxes"])
                 out.set_field("scores", res["scores"])
                 return [out]
