@@ -242,7 +242,7 @@ def main():
 
     import waldboost_amd as wb
     from waldboost_amd import _native as nat
-    from waldboost_amd.engine import PyramidEngine
+    from waldboost_amd.engine import PyramidEngine, capturing
     from waldboost_amd.synth import synth_image
     from waldboost_amd.distributed import RoundGatherer
 
@@ -353,7 +353,7 @@ def main():
             def capture_with_pack(e, out):
                 g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g):
+                with capturing(g):
                     e.run(dm)
                     e.pack(out)
                 return g
@@ -411,7 +411,7 @@ def main():
             if not mine:
                 continue
             g = torch.cuda.CUDAGraph()
-            with (torch.cuda.graph(g, stream=st) if st is not None else torch.cuda.graph(g)):
+            with (capturing(g, stream=st) if st is not None else capturing(g)):
                 for j in mine:
                     eager[j]()
             region.append((st, g))

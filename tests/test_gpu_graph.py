@@ -222,3 +222,61 @@ def test_memset_free_steps_survive_other_users_of_the_engine():
     res = M.detect_raw(dark)
     assert np.array_equal(res["alive"], ref["alive"]) and np.array_equal(bits(res["scores"]), bits(ref["scores"]))
     assert len(lv) == ref["alive"].shape[0]
+
+
+def test_capture_is_not_disturbed_by_the_cyclic_collector():
+    """A CUDAGraph that Python's cyclic collector frees in the middle of a stream capture aborts it ("operation not
+    permitted when stream is capturing", thrown from the destructor: tools/gc_capture_probe.py) -- and an engine that
+    keeps a captured step used to be such a cycle.  Every capture of the package runs inside engine.capturing: collect
+    first, collector paused until the capture has ended.  Here: a cycle holding a graph becomes garbage INSIDE a capture
+    while the collector is set to fire on every allocation."""
+    import gc
+    import torch
+    from waldboost_amd.engine import PyramidEngine, capturing
+    M = wb.load(os.path.join(GOLDEN, "models", MODELS["grad_hist"]))
+    dm = M.device_cascade()
+    H, W = 200, 260
+    e = PyramidEngine(H, W, np.uint8, 2, 8, 1, batch=1, det_capacity=16384)
+    img = synth_image(H, W, 4242)
+    e.load_images(img[None])
+    e.run(dm)
+
+    class Node:
+        pass
+
+    a, b = Node(), Node()
+    a.other, b.other = b, a                              # a cycle only the collector frees ...
+    b.graph = torch.cuda.CUDAGraph()                     # ... holding a captured graph
+    with capturing(b.graph):
+        e.run(dm)
+    torch.cuda.synchronize()
+    old = gc.get_threshold()
+    g = torch.cuda.CUDAGraph()
+    try:
+        gc.set_threshold(1, 1, 1)
+        with capturing(g):
+            e.run(dm)
+            del a, b                                     # garbage now; the collector would take it at the next allocation
+            junk = [[i] for i in range(2000)]
+            e.run(dm)
+        del junk
+    finally:
+        gc.set_threshold(*old)
+    gc.collect()
+    g.replay()
+    torch.cuda.synchronize()
+    assert_image_matches(engine_results(e, e._casc_state(dm), len(M))[0], oracle_detect(M, img))
+    # and an engine with a captured step of its own is freed by reference counting alone
+    import weakref
+    e2 = PyramidEngine(H, W, np.uint8, 2, 8, 1, batch=1, det_capacity=16384)
+    e2.load_images(img[None])
+    e2.batch_enqueue(dm)
+    e2.batch_enqueue(dm)                                 # (the second call captures and keeps the step)
+    torch.cuda.synchronize()
+    gone = weakref.ref(e2)
+    gc.disable()
+    try:
+        del e2
+        assert gone() is None
+    finally:
+        gc.enable()

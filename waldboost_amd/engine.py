@@ -8,8 +8,10 @@ batch) configuration and drives the three kernel groups through the C ABI:
 torch is used only for device memory, streams and graph capture; all compute is in
 csrc/*.hip.  Nothing here falls back to the CPU.
 """
+import contextlib
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -18,6 +20,27 @@ from .chanfunc import SPECS
 from .plan import PyramidPlan, N_CHANNELS
 
 _TORCH_DT = {}
+
+
+@contextlib.contextmanager
+def capturing(graph, **kw):
+    """``torch.cuda.graph(graph, **kw)`` with Python's cyclic collector out of the way.  An object it happens to free in
+    the middle of a stream capture -- a page-locked tensor (its allocator records events), another engine's CUDAGraph,
+    a stream -- makes HIP calls that invalidate the capture ("operation failed due to a previous error during capture");
+    torch no longer collects on entry by itself (>= 2.9).  So: collect first, then keep the collector off until the
+    capture has ended."""
+    import gc
+    import torch
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kw):
+            yield
+    finally:
+        if was:
+            gc.enable()
+
 _NO_DETECT_GRAPH = bool(int(os.environ.get("WB_NO_DETECT_GRAPH", "0")))
 _NO_RANKS = bool(os.environ.get("WB_NO_RANKS"))     # diagnostic: float32 channels + planar float tile everywhere
 # Model-specialised cascade kernels (csrc/wb_jit.hip): a cascade that has been scanned this many times on byte tiles is
@@ -299,9 +322,17 @@ class CapturedStep:
     a graph captured before such a re-allocation (it would add into freed memory) -- capture again."""
 
     def __init__(self, engine, graph):
-        self.engine, self.graph, self.generation = engine, graph, engine.generation
+        # (a weak reference: an engine that keeps its own captured step -- batch_enqueue -- must not become a reference
+        # cycle, to be freed by the collector at some arbitrary later moment)
+        self._engine, self.graph, self.generation = weakref.ref(engine), graph, engine.generation
+
+    @property
+    def engine(self):
+        return self._engine()
 
     def replay(self):
+        if self.engine is None:
+            raise RuntimeError("this captured step's engine no longer exists")
         if self.generation != self.engine.generation:
             raise RuntimeError("this captured step is stale: the engine re-allocated its control block or detection "
                                "buffer after the capture (a longer cascade, or a grown detection buffer); capture again")
@@ -674,7 +705,7 @@ class PyramidEngine:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with capturing(g):
             self.run(dm)
         return CapturedStep(self, g)
 
@@ -851,7 +882,7 @@ class PyramidEngine:
             g = torch.cuda.CUDAGraph()
             self.ensure_clean_keys()          # (the captured step holds no memset: see run)
             torch.cuda.synchronize()
-            with torch.cuda.graph(g):
+            with capturing(g):
                 self.run(dm)
                 self._final_enqueue(dm, stt)
             stt["graph"] = g
@@ -916,7 +947,7 @@ class PyramidEngine:
                 d.note_scan(nat.WB_DTYPE_RANK8 if ranks else self.spec.wb_dtype, force=True)
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g):
+            with capturing(g):
                 enqueue()
             st["graph"] = g
         st["calls"] += 1
