@@ -395,35 +395,51 @@ def main():
             main.wait_stream(comm)
 
     run_steps(0, args.warmup)
-    # One GPU, graph mode, short regions: the K steps of a timed region -- K x (memset, octaves, channels, cascade), spread
-    # over the streams exactly as run_steps spreads them -- are captured ONCE, one hipGraph per stream holding that
-    # stream's steps in order, and a region is one replay per stream: n_streams launches per region instead of K, every
-    # stream fed from its first microsecond (tools/region_launch_probe.py: 20 steps take 1.45 ms replayed step by step,
-    # 1.40 ms as four per-stream graphs).  (With several ranks the steps carry a collective each and stay separate.)
+    # Graph mode, short regions: the K steps of a timed region -- K x (octaves, channels, cascade), spread over the streams
+    # exactly as run_steps spreads them -- are captured ONCE, one hipGraph per stream holding that stream's steps in
+    # order, and a region is one replay per stream: n_streams launches per region instead of K, every stream fed from
+    # its first microsecond (tools/region_launch_probe.py: 20 steps take 1.27 ms replayed step by step, 1.22 ms as four
+    # per-stream graphs).  With several ranks every captured step also packs its engine's valid records into the step's
+    # slot of one send buffer, and the region ends with ONE all_gather of the K slots behind the streams' graphs -- the
+    # end-of-batch exchange (a rank's steps are then the same graphs as a single GPU's: measured with one rank over RCCL,
+    # --force-collective, 20 steps: 0.082 ms per step with a collective per round of 4 steps, see below for this form).
     region = None
-    use_region = args.region_graph == "on" or (args.region_graph == "auto" and args.steps <= 64)
-    if not coll and args.only == "all" and not args.no_graph and use_region:
+    gath_region = None
+    # (auto: K <= 64 -- a longer region amortises its K launches by itself; with several ranks up to 256 steps, because there
+    # the step-by-step form also pays a collective per round of P steps: 0.0745 against 0.0597 ms per step at K = 200)
+    use_region = args.region_graph == "on" or (args.region_graph == "auto" and args.steps <= (256 if coll else 64))
+    if args.only == "all" and not args.no_graph and use_region:
         eager = [(lambda e=e: e.run(dm)) for e in engines]
+        if coll:
+            gath_region = RoundGatherer(rows, args.steps, engines[0].dev)
         torch.cuda.synchronize()
         region = []
         for l, st in enumerate(lanes if n_streams > 1 else [None]):
-            mine = [i % P for i in range(args.steps) if (i % P) % n_streams == l]
+            mine = [i for i in range(args.steps) if (i % P) % n_streams == l]
             if not mine:
                 continue
             g = torch.cuda.CUDAGraph()
             with (capturing(g, stream=st) if st is not None else capturing(g)):
-                for j in mine:
-                    eager[j]()
+                for i in mine:
+                    eager[i % P]()
+                    if coll:
+                        engines[i % P].pack(gath_region.send[0][i])
             region.append((st, g))
 
         def run_region():
-            # (no cross-stream waits: a region starts after a device-wide synchronisation and ends with one)
+            # (no cross-stream waits before the replays: a region starts after a device-wide synchronisation)
             for st, g in region:
                 if st is None:
                     g.replay()
                 else:
                     with torch.cuda.stream(st):
                         g.replay()
+            if coll:
+                main = torch.cuda.current_stream()
+                for st, _ in region:
+                    if st is not None:
+                        main.wait_stream(st)
+                gath_region.gather(0)                        # every rank's K slots to every rank, inside the region
 
         # the gate again, on THESE graphs: what their replay leaves in the first and the last engine they drive
         checked = sorted({0, min(P, args.steps) - 1})
@@ -437,6 +453,20 @@ def main():
                       "engines": [dict(gate(engines[j], ""), engine=j) for j in checked]}
             for g in parity["engines"]:
                 g.pop("path")
+        if coll:
+            # ... and what the collective delivered: this rank's own block of the last step's slot, as every rank received
+            # it, against the engine that packed it
+            i_last = args.steps - 1
+            got = gath_region.merged(0, i_last, [B] * world)
+            got = got[(got["image"] >= rank * B) & (got["image"] < (rank + 1) * B)]
+            own = engines[i_last % P].sorted_detections().cpu().numpy().view(nat.DET_DTYPE).reshape(-1)
+            same = (got.size == own.size and np.array_equal(got["image"] - rank * B, own["image"]) and
+                    all(np.array_equal(got[k], own[k]) for k in ("level", "r", "c")) and
+                    np.array_equal(got["score"].view(np.uint32), own["score"].view(np.uint32)))
+            if not same:
+                raise SystemExit(f"bench: rank {rank}: the gathered detections of step {i_last} differ from the engine that packed them")
+            if parity is not None:
+                parity["gathered"] = {"step": i_last, "detections": int(own.size), "bit_exact": True}
     dts = []
     for rep in range(max(1, args.repeats)):
         torch.cuda.synchronize()
@@ -549,7 +579,9 @@ def main():
                        "channels_in_hbm": "uint8 threshold ranks of the cascade (WB_DTYPE_RANK8)" if fused else spec.dtype.name,
                        "streams": n_streams, "pool": P,
                        "cascade_kernel": (f"model-specialised (hiprtc at model load, {t_jit:.1f} s incl. cache lookup)" if jit else "generic"),
-                       "collective": "one all_gather of the P packed detection prefixes per round of P steps (side stream)" if coll else "none"},
+                       "collective": ("none" if not coll else
+                                      "one all_gather of the K steps' packed detection prefixes at the end of every timed region" if gath_region is not None
+                                      else "one all_gather of the P packed detection prefixes per round of P steps (side stream)")},
             "mpixels_per_s": world * args.steps * B * H * W / dt / 1e6,
             "images_per_s": world * args.steps * B / dt,
             "pipeline_roofline_frac": (windows / dt) * (ab["total"] / n_loc) / (HBM_PEAK_GBS * 1e9 * world),
