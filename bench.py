@@ -467,6 +467,13 @@ def main():
                 raise SystemExit(f"bench: rank {rank}: the gathered detections of step {i_last} differ from the engine that packed them")
             if parity is not None:
                 parity["gathered"] = {"step": i_last, "detections": int(own.size), "bit_exact": True}
+    # the W untimed steps once more, right in front of the timed regions: the parity gates above are seconds of host work
+    # with an idle GPU behind them, and the first timed region used to start on a GPU that had clocked down
+    # (value_spread.min 11 % under the median in round 2)
+    if region is not None:
+        run_region()
+    else:
+        run_steps(0, args.warmup)
     dts = []
     for rep in range(max(1, args.repeats)):
         torch.cuda.synchronize()
