@@ -487,7 +487,10 @@ class PyramidEngine:
                 raise ValueError(f"expected images of shape {want}, got {tuple(t.shape)}")
         if t is None:
             # (a page-locked staging buffer was measured: memcpy + DMA came out 10 % slower per Model.detect call
-            # than torch's own pipelined upload from pageable memory)
+            # than torch's own pipelined upload from pageable memory; for detect_stream's lanes, where the DMA would
+            # overlap other work, the host copy alone -- np.copyto, 45 us -- costs what the pageable upload blocks the
+            # host for, 48 us, and torch's multi-threaded CPU copy, 26 us in a tight loop, takes milliseconds once its
+            # worker threads have gone to sleep between images: tools/upload_probe.py)
             t = torch.from_numpy(np.ascontiguousarray(images))
         self.img.copy_(t, non_blocking=True)
 
