@@ -308,7 +308,44 @@ template <int S_, int TU_, int TV_, bool SMOOTH_, int NT_ = 256> struct TileGeom
 //      clamped to the level = the 'reflect' halo of convolve1d for a 1-pixel border.
 //      The RW % 64 right-most columns are done afterwards, one pixel per thread.
 //      Ends without a barrier: the caller synchronises before reading R.
-template <typename T, typename G>
+__device__ inline int reflect_index(int i, int n) {      // scipy 'reflect': (d c b a | a b c d | d c b a)
+    const int period = 2 * n;
+    i %= period;
+    if (i < 0) i += period;
+    return i >= n ? period - 1 - i : i;
+}
+
+// Coordinate i of a tile (possibly outside its level of n pixels) -> the level pixel it stands for: clamped (= the
+// 'reflect' halo of a 1-pixel border: the gradient kernels) or reflected (grad_mag's 6-pixel halo).
+template <bool REFLECT> __device__ __forceinline__ int tile_coord(int i, int n) {
+    if constexpr (REFLECT)
+        return reflect_index(i, n);
+    else
+        return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+}
+
+// ... and bounds [lo_out, hi_out] on the level pixels the coordinates lo..hi stand for (conservative under reflection:
+// they only size the staged source patch).
+template <bool REFLECT> __device__ __forceinline__ void tile_coord_range(int lo, int hi, int n, int &lo_out, int &hi_out) {
+    if constexpr (!REFLECT) {
+        lo_out = tile_coord<false>(lo, n);
+        hi_out = tile_coord<false>(hi, n);
+    } else if (lo >= 0 && hi < n) {
+        lo_out = lo;
+        hi_out = hi;
+    } else if (lo < -n || hi >= 2 * n || (lo < 0 && hi >= n)) {
+        lo_out = 0;
+        hi_out = n - 1;
+    } else if (lo < 0) {                                  // mirrored at the top / left edge: -1 - i
+        lo_out = hi < 0 ? -1 - hi : 0;
+        hi_out = hi < 0 ? -1 - lo : (hi > -1 - lo ? hi : -1 - lo);
+    } else {                                              // mirrored at the bottom / right edge: 2n - 1 - i
+        hi_out = lo >= n ? 2 * n - 1 - lo : n - 1;
+        lo_out = lo >= n ? 2 * n - 1 - hi : (lo < 2 * n - 1 - hi ? lo : 2 * n - 1 - hi);
+    }
+}
+
+template <typename T, typename G, bool REFLECT = false>
 __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &L, const T *src, const double mn,
                                               const double mx, const int ry0, const int rx0, const int rh, float *R,
                                               unsigned char *uni, float4 *rowtab, const int tid) {
@@ -368,10 +405,9 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
 #pragma unroll
     for (int c = 0; c < NCS; ++c) tcs[c] = trl;
     if constexpr (sizeof(T) == 1) {
-        int yf = ry0 < 0 ? 0 : (ry0 > L.nh - 1 ? L.nh - 1 : ry0);
-        int yl = ry0 + rh - 1; yl = yl < 0 ? 0 : (yl > L.nh - 1 ? L.nh - 1 : yl);
-        int xf = rx0 < 0 ? 0 : (rx0 > L.nw - 1 ? L.nw - 1 : rx0);
-        int xl = rx0 + RW - 1; xl = xl < 0 ? 0 : (xl > L.nw - 1 ? L.nw - 1 : xl);
+        int yf, yl, xf, xl;
+        tile_coord_range<REFLECT>(ry0, ry0 + rh - 1, L.nh, yf, yl);
+        tile_coord_range<REFLECT>(rx0, rx0 + RW - 1, L.nw, xf, xl);
         // strict down-scale on both axes: every tap pair is (i0, i0 + 1), no mirroring (plan.axis_taps), and the
         // patch extents follow from the first and last coordinate's i0 = floor((k + 0.5) * step - 0.5) -- the host's
         // own fp64 expression (the tap table holds the same numbers, but loading them here put one more
@@ -389,19 +425,16 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
         // of these loads was one more exposed memory round trip per workgroup
 #pragma unroll
         for (int c = 0; c < NCS; ++c) {
-            int x = rx0 + lane + 64 * c;
-            x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
+            const int x = tile_coord<REFLECT>(rx0 + lane + 64 * c, L.nw);
             tcs[c] = ctap[x];
         }
         {
             static_assert((RH + NW - 1) / NW <= 64, "one lane per row of the strip");
             const int RS = (rh + NW - 1) / NW;                  // rows of a wave's strip (see the row loop)
             const int kl = wave * RS + lane;
-            int ly = ry0 + (kl < rh ? kl : rh - 1);
-            ly = ly < 0 ? 0 : (ly > L.nh - 1 ? L.nh - 1 : ly);
+            const int ly = tile_coord<REFLECT>(ry0 + (kl < rh ? kl : rh - 1), L.nh);
             trl = rtap[ly];
-            int lx = rx0 + MAINW + (lane < LEFT ? lane : 0);
-            lx = lx < 0 ? 0 : (lx > L.nw - 1 ? L.nw - 1 : lx);
+            const int lx = tile_coord<REFLECT>(rx0 + MAINW + (lane < LEFT ? lane : 0), L.nw);
             tleft = ctap[lx];
         }
         if (staged) {
@@ -580,8 +613,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
         float wc0f[NCS], wc1f[NCS];
 #pragma unroll
         for (int c = 0; c < NCS; ++c) {
-            int x = rx0 + lane + 64 * c;
-            x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
+            const int x = tile_coord<REFLECT>(rx0 + lane + 64 * c, L.nw);
             tc[c] = ctap[x];
             wc0f[c] = (float)tc[c].w0;
             wc1f[c] = (float)tc[c].w1;
@@ -596,8 +628,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             for (int rb = 0; rb < RB; ++rb) {
                 int k = k0 + NW * rb;
                 k = k < rh ? k : rh - 1;                                  // clamped, unconditional loads
-                int y = ry0 + k;
-                y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
+                const int y = tile_coord<REFLECT>(ry0 + k, L.nh);
                 tr[rb] = rtap[__builtin_amdgcn_readfirstlane(y)];
                 const T *r0 = src + (int64_t)__builtin_amdgcn_readfirstlane(tr[rb].i0) * L.src_w;
                 const T *r1 = src + (int64_t)__builtin_amdgcn_readfirstlane(tr[rb].i1) * L.src_w;
@@ -637,9 +668,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
     if constexpr (LEFT > 0) {
         for (int p = tid; p < rh * LEFT; p += NT) {
             const int k = p / LEFT, q = MAINW + p - k * LEFT;
-            int y = ry0 + k, x = rx0 + q;
-            y = y < 0 ? 0 : (y > L.nh - 1 ? L.nh - 1 : y);
-            x = x < 0 ? 0 : (x > L.nw - 1 ? L.nw - 1 : x);
+            const int y = tile_coord<REFLECT>(ry0 + k, L.nh), x = tile_coord<REFLECT>(rx0 + q, L.nw);
             float out = 0.0f;
             bool ok = false;
             if constexpr (sizeof(T) == 1) {
@@ -1152,23 +1181,30 @@ struct GmGeom {
     static constexpr int NH = 5;      // half width of the 11-tap triangle
 };
 
-__device__ inline int reflect_index(int i, int n) {      // scipy 'reflect': (d c b a | a b c d | d c b a)
-    const int period = 2 * n;
-    i %= period;
-    if (i < 0) i += period;
-    return i >= n ? period - 1 - i : i;
-}
+// (the geometry resample_tile wants: the resized tile and the staged source patch -- uint8 images, any down-scale
+// below 2 -- which shares its memory with the magnitudes and the shrunk tile, both written after the resize)
+template <int S, int TU, int TV, bool SMOOTH> struct GmTile {
+    static constexpr int HS = SMOOTH ? 1 : 0, NH = GmGeom::NH;
+    static constexpr int SU = TU + 2 * HS, SV = TV + 2 * HS;      // shrunk tile incl. smooth halo
+    static constexpr int VH = S * SU, VW = S * SV;                // normalised magnitudes needed
+    static constexpr int MH = VH + 2 * NH, MW = VW + 2 * NH;      // magnitudes incl. the triangle halo
+    static constexpr int RH = MH + 2, RW = MW + 2;                // resized pixels incl. the gradient halo
+    // (512 threads: at two workgroups per CU -- what the 60 KB of LDS admit -- 16 waves per CU, like the gradient kernels)
+    static constexpr int NT = 512, NW = NT / 64;
+    static constexpr int PROWS = 2 * RH + 4, PPITCH = (2 * RW + 12 + 3) & ~3;
+};
 
 template <typename T, int S, int TU, int TV, bool SMOOTH>
-__global__ __launch_bounds__(256) void channels_gm_kernel(ChanArgs a) {
-    constexpr int HS = SMOOTH ? 1 : 0, NH = GmGeom::NH;
-    constexpr int SU = TU + 2 * HS, SV = TV + 2 * HS;      // shrunk tile incl. smooth halo
-    constexpr int VH = S * SU, VW = S * SV;                // normalised magnitudes needed
-    constexpr int MH = VH + 2 * NH, MW = VW + 2 * NH;      // magnitudes incl. the triangle halo
-    constexpr int RH = MH + 2, RW = MW + 2;                // resized pixels incl. the gradient halo
-    __shared__ float R[RH * RW];                           // resized tile; later the row-pass result [VH][MW]
-    __shared__ float Mg[MH * MW];                          // magnitudes; the centre is normalised in place
-    __shared__ float Sh[SU * SV];
+__global__ __launch_bounds__(512, 2) void channels_gm_kernel(ChanArgs a) {
+    using G = GmTile<S, TU, TV, SMOOTH>;
+    constexpr int HS = G::HS, NH = G::NH, SU = G::SU, SV = G::SV, VH = G::VH, VW = G::VW, MH = G::MH, MW = G::MW;
+    constexpr int RH = G::RH, RW = G::RW, NT = G::NT;
+    constexpr int MG_SH_BYTES = (MH * MW + SU * SV) * 4, PATCH_BYTES = sizeof(T) == 1 ? G::PROWS * G::PPITCH : 0;
+    __shared__ __attribute__((aligned(16))) float R[RH * RW];   // resized tile; later the row-pass result [VH][MW]
+    __shared__ __attribute__((aligned(16))) unsigned char uni[MG_SH_BYTES > PATCH_BYTES ? MG_SH_BYTES : PATCH_BYTES];
+    __shared__ float4 rowtab[sizeof(T) == 1 ? RH + RW % 64 : 1];
+    float *Mg = reinterpret_cast<float *>(uni);            // magnitudes; the centre is normalised in place
+    float *Sh = Mg + MH * MW;
     static_assert(VH * MW <= RH * RW, "row-pass result reuses the resized tile");
 
     const WbTile tile = a.tiles[blockIdx.x];
@@ -1179,47 +1215,17 @@ __global__ __launch_bounds__(256) void channels_gm_kernel(ChanArgs a) {
                                 : (const T *)a.oct + (int64_t)b * a.oct_stride + L.src_off;
     double mn, mx;
     clip_range<T>(a, b, L.oct, mn, mx);
-    const Tap *__restrict__ rtap = a.taps + L.tap_off;
-    const Tap *__restrict__ ctap = rtap + L.nh;
-    const bool ident = (L.src_h == L.nh) && (L.src_w == L.nw);
     const int ry0 = S * (u0 - HS) - NH - 1, rx0 = S * (v0 - HS) - NH - 1;
 
-    // ---- resized pixels (reference channels.py:132), reflected outside the level.  U pixels per thread and
-    //      pass: their tap loads, then their source loads, are all in flight together (clamped indices,
-    //      unconditional loads; the store is guarded)
-    constexpr int U = 4;
-    for (int p0 = tid; p0 < RH * RW; p0 += 256 * U) {
-        Tap tr[U], tc[U];
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            int p = p0 + 256 * k;
-            p = p < RH * RW ? p : RH * RW - 1;
-            const int kk = p / RW, q = p - kk * RW;
-            tr[k] = rtap[reflect_index(ry0 + kk, L.nh)];
-            tc[k] = ctap[reflect_index(rx0 + q, L.nw)];
-        }
-        T a00[U], a01[U], a10[U], a11[U];
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            const T *r0 = src + (int64_t)tr[k].i0 * L.src_w, *r1 = src + (int64_t)tr[k].i1 * L.src_w;
-            a00[k] = r0[tc[k].i0]; a01[k] = r0[tc[k].i1]; a10[k] = r1[tc[k].i0]; a11[k] = r1[tc[k].i1];
-        }
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            float out = 0.0f;
-            bool ok = ident && Src<T>::taps_finite(a01[k], a10[k], a11[k]);
-            if (ok) out = (mn != mn || mx != mx) ? __builtin_nanf("") : (float)a00[k];
-            if constexpr (Src<T>::kFastResample)
-                if (!ok) ok = Src<T>::fast((float)a00[k], (float)a01[k], (float)a10[k], (float)a11[k], (float)tr[k].w0,
-                                           (float)tr[k].w1, (float)tc[k].w0, (float)tc[k].w1, out);
-            if (!ok) out = Src<T>::finish(resample_f64((double)a00[k], (double)a01[k], (double)a10[k], (double)a11[k], tr[k], tc[k]), mn, mx, a.src_int);
-            if (p0 + 256 * k < RH * RW) R[p0 + 256 * k] = out;
-        }
-    }
+    // ---- resized pixels (reference channels.py:132), reflected outside the level: the channel kernels' own resample
+    //      (uint8: source patch staged in LDS, shared interpolation between rows, exact redo where the fast path's
+    //      band test asks for it) with mirrored instead of clamped coordinates
+    resample_tile<T, G, true>(a, L, src, mn, mx, ry0, rx0, RH, R, uni, rowtab, tid);
     __syncthreads();
+    if (a.dbg & 1) return;           // (WB_CHAN_DBG: phase timing -- 1 resize, 2 magnitudes, 8 / 16 the two triangle passes)
 
     // ---- gradient magnitude (channels.py:16-21, 31-32): fp32 squares, sum and square root
-    for (int p = tid; p < MH * MW; p += 256) {
+    for (int p = tid; p < MH * MW; p += NT) {
         const int k = p / MW, q = p - k * MW;
         const float *c = R + k * RW + q;                      // 3x3 patch, centre at (k+1, q+1)
         const float hc0 = Src<T>::hpass(c[0], c[RW], c[2 * RW]);              // vertical [1,2,1] at column q
@@ -1232,32 +1238,65 @@ __global__ __launch_bounds__(256) void channels_gm_kernel(ChanArgs a) {
         Mg[p] = sqrtf(gx * gx + gy * gy);
     }
     __syncthreads();
+    if (a.dbg & 2) return;
 
-    // ---- triangle filter along the rows' axis (convolve1d axis 0), result over the resized tile's memory
+    // ---- triangle filter along the rows' axis (convolve1d axis 0), result over the resized tile's memory.
+    //      Each thread forms TG outputs that are neighbours ALONG the filter: the 10 + TG magnitudes they span are read
+    //      and widened to fp64 once (one output at a time, every magnitude was read and converted eleven times);
+    //      per output the sum is formed exactly as before, term by term in scipy's order.
+    constexpr int TG = 4;
     float *Tv = R;
-    for (int p = tid; p < VH * MW; p += 256) {
-        const int k = p / MW, q = p - k * MW;
-        const float *c = Mg + (k + NH) * MW + q;
-        double t = (double)c[0] * a.tri[NH];
+    {
+        constexpr int GROUPS = (VH + TG - 1) / TG;
+        for (int p = tid; p < GROUPS * MW; p += NT) {
+            const int g = p / MW, q = p - g * MW, k0 = g * TG;
+            double x[TG + 2 * NH];
 #pragma unroll
-        for (int j = -NH; j < 0; ++j) t = t + ((double)c[j * MW] + (double)c[-j * MW]) * a.tri[NH + j];
-        Tv[p] = (float)t;
+            for (int i = 0; i < TG + 2 * NH; ++i) {
+                const int row = k0 + i < MH ? k0 + i : MH - 1;     // (rows past the tile: read, never used)
+                x[i] = (double)Mg[row * MW + q];
+            }
+#pragma unroll
+            for (int o = 0; o < TG; ++o) {
+                if (k0 + o >= VH) break;
+                double t = x[o + NH] * a.tri[NH];
+#pragma unroll
+                for (int j = -NH; j < 0; ++j) t = t + (x[o + NH + j] + x[o + NH - j]) * a.tri[NH + j];
+                Tv[(k0 + o) * MW + q] = (float)t;
+            }
+        }
     }
     __syncthreads();
+    if (a.dbg & 8) return;
     // ---- ... along the columns' axis, then mag / (norm + eps), in place at the centre of Mg
-    for (int p = tid; p < VH * VW; p += 256) {
-        const int k = p / VW, q = p - k * VW;
-        const float *c = Tv + k * MW + q + NH;
-        double t = (double)c[0] * a.tri[NH];
+    {
+        constexpr int GROUPS = (VW + TG - 1) / TG;
+        for (int p = tid; p < VH * GROUPS; p += NT) {
+            // (neighbouring lanes take neighbouring ROWS: their reads are MW floats apart -- 2-way bank conflicts; TG
+            // floats apart, along the row, they were 4-way)
+            const int qg = p / VH, k = p - qg * VH, q0 = qg * TG;
+            double x[TG + 2 * NH];
 #pragma unroll
-        for (int j = -NH; j < 0; ++j) t = t + ((double)c[j] + (double)c[-j]) * a.tri[NH + j];
-        float *m = Mg + (k + NH) * MW + q + NH;
-        *m = *m / ((float)t + a.gm_eps);
+            for (int i = 0; i < TG + 2 * NH; ++i) {
+                const int col = q0 + i < MW ? q0 + i : MW - 1;
+                x[i] = (double)Tv[k * MW + col];
+            }
+#pragma unroll
+            for (int o = 0; o < TG; ++o) {
+                if (q0 + o >= VW) break;
+                double t = x[o + NH] * a.tri[NH];
+#pragma unroll
+                for (int j = -NH; j < 0; ++j) t = t + (x[o + NH + j] + x[o + NH - j]) * a.tri[NH + j];
+                float *m = Mg + (k + NH) * MW + q0 + o + NH;
+                *m = *m / ((float)t + a.gm_eps);
+            }
+        }
     }
     __syncthreads();
+    if (a.dbg & 16) return;
 
     // ---- shrink (channels.py:55-64, fp32 ((a+b)+c)+d then /4)
-    for (int p = tid; p < SU * SV; p += 256) {
+    for (int p = tid; p < SU * SV; p += NT) {
         const int i = p / SV, j = p - i * SV;
         auto at = [&](int y, int x) { return Mg[(S * i + y + NH) * MW + S * j + x + NH]; };
         float o;
@@ -1280,7 +1319,7 @@ __global__ __launch_bounds__(256) void channels_gm_kernel(ChanArgs a) {
 
     // ---- 3x3 smooth (fp64, source order), border 0, store [u][v][1]
     float *out = reinterpret_cast<float *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
-    for (int p = tid; p < TU * TV; p += 256) {
+    for (int p = tid; p < TU * TV; p += NT) {
         const int i = p / TV, j = p - i * TV;
         const int su = u0 + i, sv = v0 + j;
         if (su >= L.u || sv >= L.v) continue;
@@ -1300,9 +1339,9 @@ template <typename T>
 int launch_gm(hipStream_t st, dim3 grid, const ChanArgs &a, int shrink, bool smooth) {
 #define WB_GM(S, TU, TV)                                                                         \
     if (smooth)                                                                                  \
-        hipLaunchKernelGGL((channels_gm_kernel<T, S, TU, TV, true>), grid, dim3(256), 0, st, a); \
+        hipLaunchKernelGGL((channels_gm_kernel<T, S, TU, TV, true>), grid, dim3(512), 0, st, a); \
     else                                                                                         \
-        hipLaunchKernelGGL((channels_gm_kernel<T, S, TU, TV, false>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((channels_gm_kernel<T, S, TU, TV, false>), grid, dim3(512), 0, st, a);
     switch (shrink) {                      // same output tiles as the other channel kernels (wb_channels_tile)
         case 1: WB_GM(1, 16, 64) break;
         case 2: WB_GM(2, 16, 64) break;
