@@ -405,9 +405,9 @@ def main():
     # --force-collective, 20 steps: 0.082 ms per step with a collective per round of 4 steps, see below for this form).
     region = None
     gath_region = None
-    # (auto: K <= 64 -- a longer region amortises its K launches by itself; with several ranks up to 256 steps, because there
+    # (auto: K <= 64 -- a longer region amortises its K launches by itself; with several ranks up to 1024 steps, because there
     # the step-by-step form also pays a collective per round of P steps: 0.0745 against 0.0597 ms per step at K = 200)
-    use_region = args.region_graph == "on" or (args.region_graph == "auto" and args.steps <= (256 if coll else 64))
+    use_region = args.region_graph == "on" or (args.region_graph == "auto" and args.steps <= (1024 if coll else 64))
     if args.only == "all" and not args.no_graph and use_region:
         eager = [(lambda e=e: e.run(dm)) for e in engines]
         if coll:
