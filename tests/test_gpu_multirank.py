@@ -127,3 +127,23 @@ def test_detect_sharded_float64_tensors_empty_shard_and_no_levels():
         assert np.array_equal(np.array(out[r][2]), ref["alive"]) and out[r][3] == (M.n_loc, M.n_weak)
         assert out[r][4][1:] == ((1 - r, 0, len(M)), (0, len(M)), "NotImplementedError")
     assert out[0][4][0] == 0 and out[1][4][0] is None
+
+
+def test_bench_multi_rank_region_with_its_exchange():
+    """bench.py's multi-rank form on the one GPU of the box (a single-rank RCCL group, --force-collective): per-stream
+    region graphs whose steps pack their detections, one all_gather at the region's end; the line must say so, carry the
+    per-rank gate results and the check of what the collective delivered."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-collective", "--steps", "8", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-through-api", "--repeats", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout
+    out = json.loads(r.stdout)
+    assert out["n_gpus"] == 1 and out["steps"] == 8 and out["value"] > 0
+    assert out["ranks"]["world_size_reported"] == 1 and out["ranks"]["parity_gate_passed"] == [True]
+    assert "end of every timed region" in out["config"]["collective"]
+    assert out["parity"]["bit_exact"] and out["parity"]["gathered"]["bit_exact"] and out["parity"]["gathered"]["step"] == 7
