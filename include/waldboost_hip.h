@@ -33,7 +33,7 @@
  *   reference waldboost/model.py:173-179 (Model.detect: per-level results concatenated for the caller)
  *        -> wb_det_pack_launch
  *   reference waldboost/model.py:136-147 + :173-179 (get_boxes on the concatenated, ordered detections)
- *        -> wb_det_finish_launch
+ *        -> wb_det_finish_launch; wb_det_finish_sorted_launch (the ordering on the device too)
  *   reference waldboost/samples.py:14-43 (gather_samples), waldboost/model.py:181-214 (Model.predict),
  *        waldboost/training.py:73-83 (DTree.apply/predict): the training-time callers of the hot path
  *        -> wb_gather_samples_launch, wb_samples_predict_launch, wb_tree_apply_launch
@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define WB_ABI_VERSION 5
+#define WB_ABI_VERSION 6
 
 #define WB_OK 0
 #define WB_ERR_INVALID (-1)     /* bad argument / malformed model */
@@ -338,6 +338,17 @@ int wb_det_pack_launch(void *stream, const WbDet *det, const uint32_t *det_count
 int wb_det_finish_launch(void *stream, const WbDet *det, const uint32_t *det_count, uint32_t shard_capacity,
                          const float *inv_scale, int n_levels, int max_rows, int max_cols, int m, int n,
                          void *out, uint32_t out_capacity);
+
+/* wb_det_finish_launch with the ordering done on the device too (model.py:173-179: the concatenated result is in level
+ * order, row-major inside a level): same arguments, same buffer layout, but when the valid records number at most
+ * min(out_capacity, 4096) the three sections are written IN KEY ORDER -- keys[i] ascending, boxes[i] / scores[i] the
+ * i-th detection of the reference's order (a key's low 26 bits then name the packed position the record came from and
+ * carry no meaning for the caller) -- and header[3] = 1.  Otherwise header[3] = 0 and the sections are exactly what
+ * wb_det_finish_launch writes (sort the keys, gather).  header[0..2] as wb_det_pack_launch writes them.  One workgroup;
+ * no host synchronisation. */
+int wb_det_finish_sorted_launch(void *stream, const WbDet *det, const uint32_t *det_count, uint32_t shard_capacity,
+                                const float *inv_scale, int n_levels, int max_rows, int max_cols, int m, int n,
+                                void *out, uint32_t out_capacity);
 
 /* One tree evaluated at explicit window origins (rs[i], cs[i]) of an HWC channel image
  * X[u][v][C] of x_dtype (WB_DTYPE_F32 / WB_DTYPE_U8); out[i] = prediction of the leaf reached

@@ -157,6 +157,39 @@ def test_pyramid_and_cascade_through_the_raw_abi():
     fs = fh[16 + 24 * Pn:].view(np.float32)[at]
     assert np.array_equal(fb.view(np.uint32), ref["boxes"].view(np.uint32))
     assert np.array_equal(fs.view(np.uint32), ref["scores"].view(np.uint32))
+    # ... and with the ordering done on the device too (wb_det_finish_sorted_launch; tests/test_gpu_finish.py has its
+    # own cases): this scan's detections are more than the 4096 it orders, so the sections are what
+    # wb_det_finish_launch wrote and header[3] says 0; the strongest 3000 of them, re-packed, arrive in order
+    assert d.size > 4096
+    fin2 = torch.full((16 + 28 * Pn,), 0xAB, dtype=torch.uint8, device=dev)
+    dims = (C.c_int(plan.n_levels), C.c_int(max(int(lv["u"]) for lv in plan.levels)), C.c_int(max(int(lv["v"]) for lv in plan.levels)),
+            C.c_int(12), C.c_int(12))
+    _check(lib, lib.wb_det_finish_sorted_launch(st, P(det2[16:].data_ptr()), P(det2.data_ptr()), C.c_uint32(cap), P(inv.data_ptr()),
+                                                *dims, P(fin2.data_ptr()), C.c_uint32(Pn)))
+    torch.cuda.synchronize()
+    f2 = fin2.cpu().numpy()
+    assert f2[:16].view(np.int32).tolist() == [d.size, int(det2[:16].max()), d.size, 0]
+    for lo, hi in ((16, 16 + 8 * d.size), (16 + 8 * Pn, 16 + 8 * Pn + 16 * d.size), (16 + 24 * Pn, 16 + 24 * Pn + 4 * d.size)):
+        assert np.array_equal(f2[lo:hi], fh[lo:hi])
+    keep = np.sort(np.argsort(-d["score"], kind="stable")[:3000])          # (d is in the reference's order: so is d[keep])
+    few = torch.zeros((16 + 64 * 64, 4), dtype=torch.int32, device=dev)
+    shard = np.arange(keep.size) % 61                                       # dealt over 61 of the 64 shards
+    cnt = np.bincount(shard, minlength=64).astype(np.int32)
+    body = np.zeros((64, 64, 4), np.int32)
+    for s_ in range(61):
+        body[s_, :cnt[s_]] = np.ascontiguousarray(d[keep[shard == s_]][::-1]).view(np.int32).reshape(-1, 4)
+    few[:16] = torch.from_numpy(cnt.reshape(16, 4)).to(dev)
+    few[16:] = torch.from_numpy(body.reshape(-1, 4)).to(dev)
+    fin3 = torch.zeros(16 + 28 * 4096, dtype=torch.uint8, device=dev)
+    _check(lib, lib.wb_det_finish_sorted_launch(st, P(few[16:].data_ptr()), P(few.data_ptr()), C.c_uint32(64), P(inv.data_ptr()),
+                                                *dims, P(fin3.data_ptr()), C.c_uint32(4096)))
+    torch.cuda.synchronize()
+    f3 = fin3.cpu().numpy()
+    assert f3[:16].view(np.int32).tolist() == [keep.size, int(cnt.max()), keep.size, 1]
+    k3 = f3[16:16 + 8 * keep.size].view(np.uint64)
+    assert np.array_equal(k3 >> np.uint64(26), keys[keep] >> np.uint64(26))
+    assert np.array_equal(f3[16 + 8 * 4096:16 + 24 * 4096].view(np.uint32).reshape(-1, 4)[:keep.size], ref["boxes"].view(np.uint32)[keep])
+    assert np.array_equal(f3[16 + 24 * 4096:].view(np.uint32)[:keep.size], ref["scores"].view(np.uint32)[keep])
     # a pyramid beyond the key's bit fields is refused, not truncated
     assert lib.wb_det_finish_launch(st, P(det2[16:].data_ptr()), P(det2.data_ptr()), C.c_uint32(cap), P(inv.data_ptr()),
                                     C.c_int(2000), C.c_int(100), C.c_int(100), C.c_int(12), C.c_int(12), P(fin.data_ptr()),

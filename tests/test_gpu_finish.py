@@ -1,0 +1,114 @@
+"""wb_det_finish_sorted_launch on synthetic detection buffers: the ordering Model.detect used to do on the host
+(reference model.py:173-179: levels in pyramid order, windows row-major inside a level; get_boxes model.py:136-147),
+done by one workgroup on the device.  Checked against NumPy for record counts around every size the bitonic network
+changes shape at (a wave's 128 elements, the powers of two, the 4096-key limit behind which the kernel leaves the
+ordering to the host)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P = C.c_void_p
+SHARDS = 64
+
+
+def _finish(lib, fn, recs_by_shard, cap, inv, m, n, out_cap, n_levels=40, mr=16384, mc=16384):
+    import torch
+    from waldboost_amd import _native as nat
+    dev = "cuda:0"
+    det = np.zeros((SHARDS * cap, 4), np.int32)
+    counts = np.zeros(SHARDS, np.uint32)
+    for s, r in enumerate(recs_by_shard):
+        det[s * cap:s * cap + min(len(r), cap)] = r[:cap].view(np.int32).reshape(-1, 4)
+        counts[s] = len(r)                                   # (a count above cap: records were dropped by the scan)
+    det_d = torch.from_numpy(det).to(dev)
+    cnt_d = torch.from_numpy(counts.view(np.int32)).to(dev)
+    inv_d = torch.from_numpy(inv).to(dev)
+    out = torch.full((16 + 28 * out_cap,), 0xCD, dtype=torch.uint8, device=dev)
+    rc = fn(None, P(det_d.data_ptr()), P(cnt_d.data_ptr()), C.c_uint32(cap), P(inv_d.data_ptr()), C.c_int(n_levels), C.c_int(mr),
+            C.c_int(mc), C.c_int(m), C.c_int(n), P(out.data_ptr()), C.c_uint32(out_cap))
+    assert rc == 0, lib.wb_last_error()
+    torch.cuda.synchronize()
+    h = out.cpu().numpy()
+    return (h[:16].view(np.int32), h[16:16 + 8 * out_cap].view(np.uint64), h[16 + 8 * out_cap:16 + 24 * out_cap].view(np.float32).reshape(-1, 4),
+            h[16 + 24 * out_cap:].view(np.float32))
+
+
+def _records(rng, total, n_levels=40):
+    from waldboost_amd import _native as nat
+    # unique (level, r, c) triples, as a scan produces them
+    flat = rng.choice(n_levels * 300 * 500, size=total, replace=False)
+    d = np.zeros(total, nat.DET_DTYPE)
+    d["level"], d["r"], d["c"] = flat // (300 * 500), (flat // 500) % 300, flat % 500
+    d["score"] = rng.standard_normal(total).astype(np.float32)
+    return d
+
+
+@pytest.mark.parametrize("total", [0, 1, 2, 63, 127, 128, 129, 255, 256, 257, 1000, 2047, 2048, 2049, 3098, 4095, 4096])
+def test_finish_sorted_orders_keys_boxes_and_scores(total):
+    from waldboost_amd import _native as nat
+    lib = nat.load()
+    rng = np.random.default_rng(total)
+    d = _records(rng, total)
+    # uneven shards, some empty
+    shard = rng.integers(0, SHARDS, total) if total % 2 else rng.choice([0, 5, 63], total)
+    by = [d[shard == s] for s in range(SHARDS)]
+    cap = max(16, max(len(b) for b in by))
+    inv = (1.0 / (1.0 + 0.09 * np.arange(40))).astype(np.float32)
+    m, n = 12, 14
+    out_cap = 4096
+    hdr, keys, boxes, scores = _finish(lib, lib.wb_det_finish_sorted_launch, by, cap, inv, m, n, out_cap)
+    assert hdr.tolist() == [total, max(len(b) for b in by) if total else 0, total, 1]
+    order = np.lexsort((d["c"], d["r"], d["level"]))
+    e = d[order]
+    k = keys[:total]
+    assert np.array_equal((k >> np.uint64(54)).astype(np.int64), e["level"])
+    assert np.array_equal(((k >> np.uint64(40)) & np.uint64(0x3fff)).astype(np.int64), e["r"])
+    assert np.array_equal(((k >> np.uint64(26)) & np.uint64(0x3fff)).astype(np.int64), e["c"])
+    assert np.array_equal(np.sort(k & np.uint64((1 << 26) - 1)), np.arange(total))       # every packed position once
+    assert np.array_equal(scores[:total].view(np.uint32), e["score"].view(np.uint32))
+    sc = inv[e["level"]]
+    c, r = e["c"].astype(np.int64), e["r"].astype(np.int64)
+    want = np.stack([c.astype(np.float32) * sc, r.astype(np.float32) * sc, (c + n).astype(np.float32) * sc, (r + m).astype(np.float32) * sc], 1)
+    assert np.array_equal(boxes[:total].view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("total,out_cap", [(4097, 8192), (6000, 8192), (3000, 2048), (5000, 4096)])
+def test_finish_sorted_leaves_large_results_to_the_host(total, out_cap):
+    """More valid records than the kernel sorts (4096) or than the buffer holds: header[3] = 0 and the sections are what
+    wb_det_finish_launch writes."""
+    from waldboost_amd import _native as nat
+    lib = nat.load()
+    rng = np.random.default_rng(total)
+    d = _records(rng, total)
+    shard = rng.integers(0, SHARDS, total)
+    by = [d[shard == s] for s in range(SHARDS)]
+    cap = max(len(b) for b in by)
+    inv = (1.0 / (1.0 + 0.09 * np.arange(40))).astype(np.float32)
+    a = _finish(lib, lib.wb_det_finish_sorted_launch, by, cap, inv, 12, 12, out_cap)
+    b = _finish(lib, lib.wb_det_finish_launch, by, cap, inv, 12, 12, out_cap)
+    present = min(total, out_cap)
+    assert a[0].tolist() == [total, cap, present, 0] and b[0].tolist() == [total, cap, present, cap]
+    for x, y in zip(a[1:], b[1:]):
+        assert np.array_equal(x[:present].view(np.uint8), y[:present].view(np.uint8))
+
+
+def test_finish_sorted_with_an_overflowed_shard():
+    """A shard whose counter ran past its capacity: its first `cap` records are valid, header[1] reports the overflow
+    (the caller grows the buffer and scans again), the valid records still arrive in order."""
+    from waldboost_amd import _native as nat
+    lib = nat.load()
+    rng = np.random.default_rng(7)
+    d = _records(rng, 900)
+    shard = rng.integers(0, 8, 900)
+    by = [d[shard == s] for s in range(SHARDS)]
+    cap = min(len(b) for b in by[:8]) - 5                    # every one of the eight used shards overflows by a few
+    inv = np.ones(40, np.float32)
+    hdr, keys, boxes, scores = _finish(lib, lib.wb_det_finish_sorted_launch, by, cap, inv, 12, 12, 4096)
+    valid = np.concatenate([b[:cap] for b in by])
+    assert hdr.tolist() == [valid.size, max(len(b) for b in by), valid.size, 1]
+    e = valid[np.lexsort((valid["c"], valid["r"], valid["level"]))]
+    assert np.array_equal(scores[:valid.size].view(np.uint32), e["score"].view(np.uint32))
+    assert np.array_equal(boxes[:valid.size, 0], e["c"].astype(np.float32))

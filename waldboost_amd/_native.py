@@ -19,7 +19,7 @@ WB_ERR_INVALID, WB_ERR_HIP, WB_ERR_UNSUPPORTED = -1, -2, -3
 WB_DET_SHARDS = 64
 WB_DTYPE_I64, WB_DTYPE_U64, WB_DTYPE_BOOL, WB_DTYPE_F16 = 9, 10, 11, 12
 WB_CHN_GRAD_HIST, WB_CHN_GRAD_HIST_4_U1, WB_CHN_GRAD_MAG_U1, WB_CHN_GRAD_MAG = 0, 1, 2, 3
-WB_ABI_VERSION = 5
+WB_ABI_VERSION = 6
 
 # numpy mirrors of the ABI structs (sizes asserted against the header's comments)
 LEVEL_DTYPE = np.dtype([
@@ -76,6 +76,7 @@ SYMBOLS = {
     "wb_boxes_launch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int, C.c_int, _P, _P]),
     "wb_det_pack_launch": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32]),
     "wb_det_finish_launch": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_uint32]),
+    "wb_det_finish_sorted_launch": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_uint32]),
     "wb_selftest_projection": (C.c_int, [_P, _P]),
 }
 

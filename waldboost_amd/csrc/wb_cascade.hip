@@ -313,6 +313,131 @@ __global__ __launch_bounds__(256) void det_finish_kernel(const WbDet *det, const
     }
 }
 
+// det_finish_kernel with the ordering done here as well (wb_det_finish_sorted_launch).  The keys are unique, so a record's
+// place in the reference's order is the NUMBER OF SMALLER KEYS: every workgroup gathers all n <= WB_FINISH_SORT_MAX keys
+// into LDS (50 KB of L2 reads, every load in flight at once: a thread finds the shard of its flat index by bisection of
+// the shards' prefix sums), ranks its own 32 records against them -- eight threads per record, each over an eighth of
+// the keys, the keys as LDS broadcast reads -- and writes key, box and score straight to the record's rank: up to 128
+// workgroups of 32 records on as many CUs.  (One workgroup sorting in LDS -- a bitonic network, built first --
+// took 37 us for the same: 78 stages x 64 KB through ONE CU's LDS.)  The host takes slices instead of sorting and
+// gathering (0.03 ms of a 0.23 ms Model.detect call, and the step that bounded Model.detect_stream at batch 1).
+// header[3] = 1 says so.  More valid records than WB_FINISH_SORT_MAX (or than out_cap): the sections are written
+// unordered, exactly as det_finish_kernel leaves them, header[3] = 0.
+#define WB_FINISH_SORT_MAX 4096
+#define WB_FINISH_TPR 8                                        // threads per record
+#define WB_FINISH_RPW (256 / WB_FINISH_TPR)                    // records per workgroup
+#define WB_FINISH_GRID (WB_FINISH_SORT_MAX / WB_FINISH_RPW)    // >= WB_DET_SHARDS: the unordered form wants a workgroup per shard
+__global__ __launch_bounds__(256) void det_finish_sorted_kernel(const WbDet *det, const uint32_t *det_count, uint32_t cap,
+                                                                 const float *inv_scale, int m, int n, int32_t *out, uint32_t out_cap) {
+    static_assert(WB_DET_SHARDS == 64, "one counter per lane of a wave, one workgroup per shard");
+    __shared__ unsigned long long skey[WB_FINISH_SORT_MAX];
+    __shared__ uint32_t sbefore[65];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wg = blockIdx.x;
+    const uint32_t raw = det_count[lane];
+    const uint32_t mine = raw < cap ? raw : cap;
+    uint32_t before = 0, total = 0, worst = 0;                // before: valid records in the shards in front of shard `lane`
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)mine, s);
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)raw, s);
+        before += s < lane ? c : 0u;
+        total += c;
+        worst = r > worst ? r : worst;
+    }
+    const bool ordered = total <= out_cap && total <= WB_FINISH_SORT_MAX;
+    if (wg == 0 && tid == 0) {
+        out[0] = (int32_t)total;
+        out[1] = (int32_t)worst;
+        out[2] = (int32_t)(total < out_cap ? total : out_cap);
+        out[3] = ordered ? 1 : 0;
+    }
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(out + 4);
+    float4 *boxes = reinterpret_cast<float4 *>(keys + out_cap);
+    float *scores = reinterpret_cast<float *>(boxes + out_cap);
+    auto key_of = [](const WbDet &d, uint32_t at) {
+        return ((unsigned long long)(uint32_t)d.level << 54) | ((unsigned long long)d.r << 40) | ((unsigned long long)d.c << 26) |
+               (unsigned long long)at;
+    };
+    auto box_of = [&](uint32_t level, uint32_t r, uint32_t c) {
+        const float sc = inv_scale[level];
+        return make_float4((float)c * sc, (float)r * sc, (float)((int)c + n) * sc, (float)((int)r + m) * sc);
+    };
+    if (!ordered) {                                           // (grid-uniform) det_finish_kernel's body: this workgroup's shard
+        if (wg >= WB_DET_SHARDS) return;
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)mine, wg), b0 = (uint32_t)__builtin_amdgcn_readlane((int)before, wg);
+        const WbDet *src = det + (size_t)wg * cap;
+        for (uint32_t i = tid; i < cnt; i += 256) {
+            const uint32_t at = b0 + i;
+            if (at >= out_cap) break;
+            const WbDet d = src[i];
+            keys[at] = key_of(d, at);
+            boxes[at] = box_of((uint32_t)d.level, d.r, d.c);
+            scores[at] = d.score;
+        }
+        return;
+    }
+    if (total <= (uint32_t)(WB_FINISH_RPW * wg)) return;      // (this workgroup's records start behind the last one)
+    if (tid < 64) sbefore[tid] = before;
+    if (tid == 0) sbefore[64] = total;
+    __syncthreads();
+    // where flat position q lies: the last shard s with sbefore[s] <= q (empty shards share a prefix with their successor
+    // and are stepped over: the LAST such shard is the one that holds records)
+    auto locate = [&](uint32_t q) {
+        uint32_t lo = 0;
+#pragma unroll
+        for (uint32_t step = 32; step > 0; step >>= 1)
+            if (sbefore[lo + step] <= q) lo += step;
+        return det + (size_t)lo * cap + (q - sbefore[lo]);
+    };
+    // all keys into LDS: WB_FINISH_SORT_MAX / 256 records per thread, every load requested before the first is used
+    constexpr int PER = WB_FINISH_SORT_MAX / 256;
+    {
+        uint2 lr[PER];                                        // (level, r | c << 16): the words of a record that make its key
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t q = (uint32_t)tid + 256u * k;
+            lr[k] = make_uint2(0u, 0u);
+            if (q < total) {
+                const uint32_t *w = reinterpret_cast<const uint32_t *>(locate(q));
+                lr[k] = make_uint2(w[1], w[2]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t q = (uint32_t)tid + 256u * k;
+            if (q < total)
+                skey[q] = ((unsigned long long)lr[k].x << 54) | ((unsigned long long)(lr[k].y & 0xffffu) << 40) |
+                          ((unsigned long long)(lr[k].y >> 16) << 26) | (unsigned long long)q;
+        }
+    }
+    __syncthreads();
+    // TPR threads per record, each over the keys j = part, part + TPR, ... (a wave's records read the same TPR keys at a
+    // time: LDS broadcasts), eight keys per thread and pass in flight
+    constexpr uint32_t TPR = WB_FINISH_TPR, UN = 8;
+    const uint32_t q = (uint32_t)(WB_FINISH_RPW * wg) + (uint32_t)tid / TPR, part = (uint32_t)tid % TPR;
+    const bool live = q < total;
+    const unsigned long long me = skey[live ? q : 0u];
+    uint32_t smaller = 0;
+    const uint32_t nfull = total - total % (TPR * UN);        // whole passes; the rest key by key
+    for (uint32_t j = part; j < nfull; j += TPR * UN) {
+        unsigned long long kk[UN];
+#pragma unroll
+        for (uint32_t u = 0; u < UN; ++u) kk[u] = skey[j + TPR * u];
+#pragma unroll
+        for (uint32_t u = 0; u < UN; ++u) smaller += kk[u] < me ? 1u : 0u;
+    }
+    for (uint32_t j = nfull + part; j < total; j += TPR) smaller += skey[j] < me ? 1u : 0u;
+#pragma unroll
+    for (uint32_t d = 1; d < TPR; d <<= 1) smaller += (uint32_t)__shfl_xor((int)smaller, (int)d);
+    if (live && part == 0) {
+        const WbDet d = *locate(q);
+        keys[smaller] = me;
+        boxes[smaller] = box_of((uint32_t)d.level, d.r, d.c);
+        scores[smaller] = d.score;
+    }
+}
+
 #define WB_CASC_CONFIGS(X) X(8, 4) X(4, 4) X(2, 4) X(1, 4) X(8, 8) X(4, 8) X(2, 8) X(1, 8) X(2, 16) X(1, 16)
 
 template <int D>
@@ -563,6 +688,25 @@ extern "C" int wb_det_finish_launch(void *stream, const WbDet *det, const uint32
         return WB_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL(det_finish_kernel, dim3(WB_DET_SHARDS), dim3(256), 0, (hipStream_t)stream, det, det_count,
+                       shard_capacity, inv_scale, m, n, reinterpret_cast<int32_t *>(out), out_capacity);
+    WB_HIP_CHECK(hipGetLastError());
+    return WB_OK;
+}
+
+extern "C" int wb_det_finish_sorted_launch(void *stream, const WbDet *det, const uint32_t *det_count, uint32_t shard_capacity,
+                                           const float *inv_scale, int n_levels, int max_rows, int max_cols, int m, int n,
+                                           void *out, uint32_t out_capacity) {
+    WB_REQUIRE(det_count && out && inv_scale, "wb_det_finish_sorted_launch: null pointer");
+    WB_REQUIRE(det || shard_capacity == 0, "wb_det_finish_sorted_launch: det is null but capacity > 0");
+    WB_REQUIRE(reinterpret_cast<uintptr_t>(out) % 16 == 0, "wb_det_finish_sorted_launch: out must be 16-byte aligned");
+    WB_REQUIRE(out_capacity % 2 == 0, "wb_det_finish_sorted_launch: out_capacity must be even (16-byte aligned sections)");
+    if (n_levels > (1 << 10) || max_rows > (1 << 14) || max_cols > (1 << 14) || out_capacity > (1u << 26)) {
+        wb_set_error("wb_det_finish_sorted_launch: %d levels of up to %d x %d windows, %u records do not fit the 10/14/14/26-bit key",
+                     n_levels, max_rows, max_cols, out_capacity);
+        return WB_ERR_UNSUPPORTED;
+    }
+    static_assert(WB_FINISH_GRID >= WB_DET_SHARDS, "a workgroup per shard for the unordered form");
+    hipLaunchKernelGGL(det_finish_sorted_kernel, dim3(WB_FINISH_GRID), dim3(256), 0, (hipStream_t)stream, det, det_count,
                        shard_capacity, inv_scale, m, n, reinterpret_cast<int32_t *>(out), out_capacity);
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;

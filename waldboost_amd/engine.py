@@ -806,7 +806,7 @@ class PyramidEngine:
         return True
 
     def _final_enqueue(self, dm, stt):
-        """wb_det_finish_launch + the two read-back copies into page-locked memory (no synchronisation).  The buffers
+        """wb_det_finish_sorted_launch + the two read-back copies into page-locked memory (no synchronisation).  The buffers
         belong to the cascade's scan state: several cascades can be scanned back to back on one engine (waldboost.detect)
         and read back with ONE wait -- the shared detection buffer is free again as soon as this launch has run."""
         import torch
@@ -819,10 +819,12 @@ class PyramidEngine:
             stt["h_final_views"] = (h[:16].view(np.int32), h[16:16 + 8 * P].view(np.uint64),
                                     h[16 + 8 * P:16 + 24 * P].view(np.float32).reshape(P, 4), h[16 + 24 * P:].view(np.float32))
             stt["h_alive"] = torch.empty(stt["alive"].shape, dtype=torch.int32).pin_memory()
-        nat.check(self.lib.wb_det_finish_launch(nat.stream_ptr(), nat.ptr(self.detb.recs), nat.ptr(self.detb.counts),
-                                                self.detb.cap, nat.ptr(self._inv_scales_d), self.plan.n_levels,
-                                                self._final_dims[1], self._final_dims[2], dm.m, dm.n,
-                                                nat.ptr(stt["final"]), self._FETCH_ROWS), "wb_det_finish_launch")
+        # (ordered on the device: one workgroup sorts the keys in LDS and writes keys, boxes and scores in the reference's
+        # order whenever they number at most 4096 -- header[3] says whether it did)
+        nat.check(self.lib.wb_det_finish_sorted_launch(nat.stream_ptr(), nat.ptr(self.detb.recs), nat.ptr(self.detb.counts),
+                                                       self.detb.cap, nat.ptr(self._inv_scales_d), self.plan.n_levels,
+                                                       self._final_dims[1], self._final_dims[2], dm.m, dm.n,
+                                                       nat.ptr(stt["final"]), self._FETCH_ROWS), "wb_det_finish_sorted_launch")
         stt["h_final"].copy_(stt["final"], non_blocking=True)
         stt["h_alive"].copy_(stt["alive"], non_blocking=True)
 
@@ -830,8 +832,9 @@ class PyramidEngine:
         """fetch() for Model.detect on ONE image: wb_det_finish_launch leaves sort keys, boxes and scores of all
         valid records behind one header; they come back with ONE copy and ONE event wait together with alive[B, L, T].
         Returns (keys uint64 [n] (level << 54 | r << 40 | c << 26 | position), boxes float32 [rows, 4], scores
-        float32 [rows], alive int64 [B, L, T]) -- keys unsorted, boxes / scores indexed by a key's position -- or
-        None when this form does not apply (a batch, a pyramid beyond the key's bit fields, more than _FETCH_ROWS
+        float32 [rows], alive int64 [B, L, T], ordered) -- ordered: the device sorted them (keys ascending, boxes[i] /
+        scores[i] the i-th detection: at most 4096 of them); else keys unsorted, boxes / scores indexed by a key's
+        position.  The arrays are views of the page-locked read-back buffer: copy what is kept.  None when this form does not apply (a batch, a pyramid beyond the key's bit fields, more than _FETCH_ROWS
         detections): use fetch() then.  Grows the detection buffer and scans again if a shard overflowed.
         enqueued: the launch and the copies are already in the stream (detect_run's graph replay).
         stream: that stream, when it is not the current one -- then only the wait happens here, and False is returned
@@ -860,7 +863,7 @@ class PyramidEngine:
         if total > P:
             return None
         alive = stt["h_alive"].numpy()[:, :, :T].astype(np.int64)
-        return keys[:total], boxes, scores, alive
+        return keys[:total], boxes, scores, alive, bool(hdr[3])
 
     def detect_run(self, dm):
         """Model.detect's whole device sequence for the resident image -- one memset, octaves, channels, cascade,
@@ -970,7 +973,7 @@ class PyramidEngine:
                 st["fails"] += 1                              # (tried again after 16, 32, 64 ... calls)
                 st["skip"] = min(8 << st["fails"], 4096)
                 return None
-            out.append((keys[:total], boxes, scores, stt["h_alive"].numpy()[:, :, :d.n_stages].astype(np.int64)))
+            out.append((keys[:total], boxes, scores, stt["h_alive"].numpy()[:, :, :d.n_stages].astype(np.int64), bool(hdr[3])))
         st["fails"] = 0
         return out
 

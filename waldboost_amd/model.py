@@ -217,17 +217,22 @@ class Model:
         if fin is False:
             fin = eng.fetch_final(dm, stt)                # ONE host synchronisation: sort keys, boxes, scores, statistics
         if fin is not None:
-            # get_boxes and the (level, r, c) keys were formed on the device (wb_det_finish_launch): the host sorts
-            # the keys -- unique, so any sort kind gives the reference order -- and gathers
-            keys, boxes_d, scores_d, alive = fin
+            # get_boxes and the (level, r, c) keys were formed on the device (wb_det_finish_sorted_launch) and -- up to 4096
+            # detections -- put in the reference's order there: the host copies slices out of the read-back buffer.
+            # Otherwise it sorts the keys -- unique, so any sort kind gives the reference order -- and gathers
+            keys, boxes_d, scores_d, alive, ordered = fin
             alive = alive[0].reshape(eng.plan.n_levels, T)
             if "n_loc" not in stt:
                 stt["n_loc"] = eng.plan.n_loc(m, n)
             self.n_loc += stt["n_loc"]
             self.n_weak += int(alive.sum())
-            ks = np.sort(keys)
-            at = (ks & np.uint64((1 << 26) - 1)).astype(np.intp)
-            res = dict(boxes=boxes_d[at], scores=scores_d[at], alive=alive, scales=list(eng.plan.scales))
+            if ordered:
+                ks = keys                                  # (the fields below are taken out as new arrays)
+                res = dict(boxes=boxes_d[:keys.size].copy(), scores=scores_d[:keys.size].copy(), alive=alive, scales=list(eng.plan.scales))
+            else:
+                ks = np.sort(keys)
+                at = (ks & np.uint64((1 << 26) - 1)).astype(np.intp)
+                res = dict(boxes=boxes_d[at], scores=scores_d[at], alive=alive, scales=list(eng.plan.scales))
             if full:
                 res.update(level=(ks >> np.uint64(54)).astype(np.int32),
                            r=((ks >> np.uint64(40)) & np.uint64(0x3fff)).astype(np.int64),
