@@ -33,7 +33,8 @@
  *   reference waldboost/model.py:173-179 (Model.detect: per-level results concatenated for the caller)
  *        -> wb_det_pack_launch
  *   reference waldboost/model.py:136-147 + :173-179 (get_boxes on the concatenated, ordered detections)
- *        -> wb_det_finish_launch; wb_det_finish_sorted_launch (the ordering on the device too)
+ *        -> wb_det_finish_launch; wb_det_finish_sorted_launch (the ordering on the device too);
+ *           wb_det_order_batch_launch (the same per image of a batch)
  *   reference waldboost/samples.py:14-43 (gather_samples), waldboost/model.py:181-214 (Model.predict),
  *        waldboost/training.py:73-83 (DTree.apply/predict): the training-time callers of the hot path
  *        -> wb_gather_samples_launch, wb_samples_predict_launch, wb_tree_apply_launch
@@ -349,6 +350,20 @@ int wb_det_finish_launch(void *stream, const WbDet *det, const uint32_t *det_cou
 int wb_det_finish_sorted_launch(void *stream, const WbDet *det, const uint32_t *det_count, uint32_t shard_capacity,
                                 const float *inv_scale, int n_levels, int max_rows, int max_cols, int m, int n,
                                 void *out, uint32_t out_capacity);
+
+/* The same for a BATCH (the reference's detection loop over files, scripts/waldboost-detect.py:64-67, taken a batch at a
+ * time): the shards' records are first split by image into buckets (scratch), then every image's bucket is ordered and
+ * finished like a single image's shards.  Two launches, no host synchronisation.
+ *   scratch  dev, 16-byte aligned, >= n_images * (256 + 16 * out_capacity) bytes
+ *   out      dev, 16-byte aligned:  int32 info[4] = (valid records of all shards, fullest shard -- above
+ *            shard_capacity: records were dropped, scan again --, n_images, out_capacity)
+ *            | per image b, 16 + 28 * out_capacity bytes: header[4] | keys | boxes | scores exactly as
+ *              wb_det_finish_sorted_launch writes them for ONE image with capacity out_capacity: header[0] = the image's
+ *              detections, header[1] the same (above out_capacity: they did not fit), header[3] = 1 when in key order
+ *   out_capacity  per image; a multiple of 4, <= 2^26 (ordered up to 4096 detections per image) */
+int wb_det_order_batch_launch(void *stream, const WbDet *det, const uint32_t *det_count, uint32_t shard_capacity,
+                              int n_images, const float *inv_scale, int n_levels, int max_rows, int max_cols, int m, int n,
+                              void *scratch, size_t scratch_bytes, void *out, uint32_t out_capacity);
 
 /* One tree evaluated at explicit window origins (rs[i], cs[i]) of an HWC channel image
  * X[u][v][C] of x_dtype (WB_DTYPE_F32 / WB_DTYPE_U8); out[i] = prediction of the leaf reached

@@ -138,12 +138,16 @@ def test_stream_grows_a_lane_whose_detection_buffer_overflows():
 
 
 @pytest.mark.parametrize("lanes,batch", [(3, 4), (2, 3), (1, 2), (3, 16)])
-@pytest.mark.parametrize("device_post", [False, True])
-def test_stream_in_batches_equals_detect_per_image(lanes, batch, device_post, monkeypatch):
+@pytest.mark.parametrize("post", ["ordered", "host", "device"])
+def test_stream_in_batches_equals_detect_per_image(lanes, batch, post, monkeypatch):
     """Batches fill image by image; a shape change, the tiny image and the end of the sequence send partly filled ones
-    (whose stale slots must not show).  device_post: ordering and boxes on the device (as with many detections)."""
+    (whose stale slots must not show).  post: where a batch's results are put in order -- "ordered": split by image and
+    ordered by wb_det_order_batch_launch (the default); the forms it falls back to when an image holds more than 4096
+    detections: "host" (few detections: from the packed read-back) and "device" (torch sort + wb_boxes_launch)."""
     import waldboost_amd.model as wm
-    if device_post:
+    if post != "ordered":
+        monkeypatch.setattr(wm, "_ORDER_BATCH", False)
+    if post == "device":
         monkeypatch.setattr(wm, "_HOST_POST_BATCH", 0)
     images = mixed_images() * 2
     A, B = load(), load()
@@ -193,6 +197,7 @@ def test_stream_with_more_detections_than_one_read_back_holds(batch, monkeypatch
     from waldboost_amd import engine as E
     E._ENGINES.clear()                                  # (cached engines hold read-back buffers of the usual size)
     monkeypatch.setattr(E.PyramidEngine, "_FETCH_ROWS", 64)
+    monkeypatch.setattr(E.PyramidEngine, "_ORDER_ROWS", 64)   # (a batch's per-image blocks likewise: the batch goes the older way)
     try:
         M, N = load(), load()
         ims = [synth_image(240, 320, 950 + i) for i in range(7)]

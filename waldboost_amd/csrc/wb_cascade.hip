@@ -327,13 +327,19 @@ __global__ __launch_bounds__(256) void det_finish_kernel(const WbDet *det, const
 #define WB_FINISH_TPR 8                                        // threads per record
 #define WB_FINISH_RPW (256 / WB_FINISH_TPR)                    // records per workgroup
 #define WB_FINISH_GRID (WB_FINISH_SORT_MAX / WB_FINISH_RPW)    // >= WB_DET_SHARDS: the unordered form wants a workgroup per shard
+// blockIdx.y: the image of a batch (wb_det_order_batch_launch) -- its own 64 counters, record region and output block
+// (img_det / img_out: their distances in records / int32 words); a single image launches one row.
 __global__ __launch_bounds__(256) void det_finish_sorted_kernel(const WbDet *det, const uint32_t *det_count, uint32_t cap,
-                                                                 const float *inv_scale, int m, int n, int32_t *out, uint32_t out_cap) {
+                                                                 const float *inv_scale, int m, int n, int32_t *out, uint32_t out_cap,
+                                                                 size_t img_det, size_t img_out) {
     static_assert(WB_DET_SHARDS == 64, "one counter per lane of a wave, one workgroup per shard");
     __shared__ unsigned long long skey[WB_FINISH_SORT_MAX];
     __shared__ uint32_t sbefore[65];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wg = blockIdx.x;
+    det_count += (size_t)blockIdx.y * WB_DET_SHARDS;
+    det += (size_t)blockIdx.y * img_det;
+    out += (size_t)blockIdx.y * img_out;
     const uint32_t raw = det_count[lane];
     const uint32_t mine = raw < cap ? raw : cap;
     uint32_t before = 0, total = 0, worst = 0;                // before: valid records in the shards in front of shard `lane`
@@ -436,6 +442,78 @@ __global__ __launch_bounds__(256) void det_finish_sorted_kernel(const WbDet *det
         boxes[smaller] = box_of((uint32_t)d.level, d.r, d.c);
         scores[smaller] = d.score;
     }
+}
+
+// A batch's detections by image (the step in front of det_finish_sorted_kernel for a batch): workgroup b walks ALL valid
+// records of the shards -- flat positions, the shard of a position by bisection of the prefix sums, several loads in
+// flight per thread -- and appends those of image b to bucket b (wave-aggregated: one LDS atomic per wave and pass).
+// The order inside a bucket is whatever the atomics gave; ranking by key does not depend on it.  bucket_count[b][0] =
+// the image's record count (above bucket_cap: the finishing kernel reports the overflow), [b][1..63] = 0: a bucket reads
+// as a shard set whose first shard holds everything.  info = (valid records, fullest shard, images, bucket_cap).
+__global__ __launch_bounds__(1024) void det_bucket_kernel(const WbDet *det, const uint32_t *det_count, uint32_t cap, WbDet *bucket,
+                                                           uint32_t bucket_cap, uint32_t *bucket_count, int32_t *info) {
+    static_assert(WB_DET_SHARDS == 64, "one counter per lane of a wave");
+    __shared__ uint32_t sbefore[65];
+    __shared__ uint32_t n_img;
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const uint32_t raw = det_count[lane];
+    const uint32_t mine = raw < cap ? raw : cap;
+    uint32_t before = 0, total = 0, worst = 0;
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)mine, s);
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)raw, s);
+        before += s < lane ? c : 0u;
+        total += c;
+        worst = r > worst ? r : worst;
+    }
+    if (b == 0 && tid == 0) {
+        info[0] = (int32_t)total;
+        info[1] = (int32_t)worst;
+        info[2] = (int32_t)gridDim.x;
+        info[3] = (int32_t)bucket_cap;
+    }
+    if (tid < 64) sbefore[tid] = before;
+    if (tid == 0) {
+        sbefore[64] = total;
+        n_img = 0;
+    }
+    __syncthreads();
+    auto locate = [&](uint32_t q) {
+        uint32_t lo = 0;
+#pragma unroll
+        for (uint32_t step = 32; step > 0; step >>= 1)
+            if (sbefore[lo + step] <= q) lo += step;
+        return det + (size_t)lo * cap + (q - sbefore[lo]);
+    };
+    WbDet *dst = bucket + (size_t)b * bucket_cap;
+    constexpr int U = 4;
+    for (uint32_t q0 = 0; q0 < total; q0 += 1024 * U) {      // (workgroup-uniform bounds)
+        uint4 rec[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + (uint32_t)tid + 1024u * u;
+            ok[u] = q < total;
+            rec[u] = make_uint4(0xffffffffu, 0u, 0u, 0u);
+            if (ok[u]) rec[u] = *reinterpret_cast<const uint4 *>(locate(q));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool take = ok[u] && (int)rec[u].x == b;
+            const unsigned long long mask = __ballot(take);
+            if (mask == 0ull) continue;                       // (wave-uniform)
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&n_img, (uint32_t)__popcll(mask));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (take) {
+                const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                if (slot < bucket_cap) *reinterpret_cast<uint4 *>(dst + slot) = rec[u];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 64) bucket_count[(size_t)b * WB_DET_SHARDS + tid] = tid == 0 ? n_img : 0u;
 }
 
 #define WB_CASC_CONFIGS(X) X(8, 4) X(4, 4) X(2, 4) X(1, 4) X(8, 8) X(4, 8) X(2, 8) X(1, 8) X(2, 16) X(1, 16)
@@ -707,7 +785,38 @@ extern "C" int wb_det_finish_sorted_launch(void *stream, const WbDet *det, const
     }
     static_assert(WB_FINISH_GRID >= WB_DET_SHARDS, "a workgroup per shard for the unordered form");
     hipLaunchKernelGGL(det_finish_sorted_kernel, dim3(WB_FINISH_GRID), dim3(256), 0, (hipStream_t)stream, det, det_count,
-                       shard_capacity, inv_scale, m, n, reinterpret_cast<int32_t *>(out), out_capacity);
+                       shard_capacity, inv_scale, m, n, reinterpret_cast<int32_t *>(out), out_capacity, (size_t)0, (size_t)0);
+    WB_HIP_CHECK(hipGetLastError());
+    return WB_OK;
+}
+
+extern "C" int wb_det_order_batch_launch(void *stream, const WbDet *det, const uint32_t *det_count, uint32_t shard_capacity,
+                                         int n_images, const float *inv_scale, int n_levels, int max_rows, int max_cols, int m,
+                                         int n, void *scratch, size_t scratch_bytes, void *out, uint32_t out_capacity) {
+    WB_REQUIRE(det_count && out && inv_scale && scratch, "wb_det_order_batch_launch: null pointer");
+    WB_REQUIRE(det || shard_capacity == 0, "wb_det_order_batch_launch: det is null but capacity > 0");
+    WB_REQUIRE(n_images >= 1 && n_images <= 65535, "wb_det_order_batch_launch: 1 .. 65535 images");
+    WB_REQUIRE(reinterpret_cast<uintptr_t>(out) % 16 == 0 && reinterpret_cast<uintptr_t>(scratch) % 16 == 0,
+               "wb_det_order_batch_launch: out and scratch must be 16-byte aligned");
+    WB_REQUIRE(out_capacity % 4 == 0 && out_capacity >= 4, "wb_det_order_batch_launch: out_capacity must be a multiple of 4 (16-byte aligned blocks)");
+    if (n_levels > (1 << 10) || max_rows > (1 << 14) || max_cols > (1 << 14) || out_capacity > (1u << 26)) {
+        wb_set_error("wb_det_order_batch_launch: %d levels of up to %d x %d windows, %u records do not fit the 10/14/14/26-bit key",
+                     n_levels, max_rows, max_cols, out_capacity);
+        return WB_ERR_UNSUPPORTED;
+    }
+    const size_t counts_bytes = (size_t)n_images * WB_DET_SHARDS * 4, need = counts_bytes + (size_t)n_images * out_capacity * sizeof(WbDet);
+    if (scratch_bytes < need) {
+        wb_set_error("wb_det_order_batch_launch: scratch holds %zu bytes, %d images of %u records want %zu", scratch_bytes, n_images,
+                     out_capacity, need);
+        return WB_ERR_INVALID;
+    }
+    uint32_t *bucket_count = reinterpret_cast<uint32_t *>(scratch);
+    WbDet *bucket = reinterpret_cast<WbDet *>(reinterpret_cast<unsigned char *>(scratch) + counts_bytes);
+    int32_t *info = reinterpret_cast<int32_t *>(out);
+    hipLaunchKernelGGL(det_bucket_kernel, dim3(n_images), dim3(1024), 0, (hipStream_t)stream, det, det_count, shard_capacity, bucket,
+                       out_capacity, bucket_count, info);
+    hipLaunchKernelGGL(det_finish_sorted_kernel, dim3(WB_FINISH_GRID, n_images), dim3(256), 0, (hipStream_t)stream, bucket, bucket_count,
+                       out_capacity, inv_scale, m, n, info + 4, out_capacity, (size_t)out_capacity, (size_t)(4 + 7 * (size_t)out_capacity));
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;
 }

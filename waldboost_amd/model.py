@@ -20,6 +20,8 @@ from .training import DTree, _REBINDS
 # above this many detections per call the compaction, ordering and boxes stay on the GPU
 _HOST_POST_MAX = 1 << 16
 _HOST_POST_BATCH = 2048          # detect_stream's batches: more detections than this are ordered on the device
+# detect_stream's batches: split by image and ordered by wb_det_order_batch_launch (tests and WB_NO_ORDER_BATCH switch it off)
+_ORDER_BATCH = os.environ.get("WB_NO_ORDER_BATCH") is None
 
 
 def symbol_name(s):
@@ -367,9 +369,24 @@ class Model:
 
     def _collect_batch(self, eng, dm, stt, count):
         """Boxes of images [0, count) of the batch `eng` has just scanned (detect_stream; the slots behind `count` hold
-        earlier images, whose results are dropped).  Few detections: ordered on the host from the one read-back;
-        otherwise ordered, and their boxes formed, on the device (wb_boxes_launch).  Updates n_loc / n_weak."""
+        earlier images, whose results are dropped).  Split by image, ordered and finished on the device
+        (wb_det_order_batch_launch) with one read-back; an image with more than 4096 detections sends the batch the
+        older way: few detections ordered on the host from the one read-back, otherwise ordered, and their boxes formed,
+        on the device (wb_boxes_launch).  Updates n_loc / n_weak."""
         m, n, Cc = self.shape
+        # split by image, ordered and finished on the device (wb_det_order_batch_launch: up to 4096 detections per
+        # image): per image a copy of its slices of the one read-back
+        res = eng.fetch_ordered_batch(dm, stt) if _ORDER_BATCH else None   # ONE host synchronisation (overflow: grows and scans again)
+        if res is not None:
+            per_image, alive = res
+            self.n_loc += count * eng.plan.n_loc(m, n)
+            self.n_weak += int(alive[:count].sum())
+            out = []
+            for keys, boxes, scores in per_image[:count]:
+                bx = Boxes(boxes.copy())
+                bx.set_field("scores", scores.copy())
+                out.append(bx)
+            return out
         got, alive = eng.fetch(dm, stt, limit=_HOST_POST_BATCH)   # ONE host synchronisation (overflow: grows and scans again)
         self.n_loc += count * eng.plan.n_loc(m, n)
         self.n_weak += int(alive[:count].sum())
