@@ -3,6 +3,7 @@
 ``predict_on_image``, ``channels``, ``scan_channels``, ``get_boxes``, ``eval_cost``/``reset``
 and the zlib+protobuf ``.pb`` format.  The dense cascade scan runs in csrc/wb_cascade.hip.
 """
+import os
 import zlib
 
 import numpy as np
