@@ -868,28 +868,23 @@ class PyramidEngine:
 
     _ORDER_ROWS = 4096               # per image: what wb_det_order_batch_launch orders (more: the caller's other path)
 
-    def fetch_ordered_batch(self, dm, stt):
-        """fetch() for a batch whose results are wanted image by image in the reference's order (Model.detect_stream's
-        batches): wb_det_order_batch_launch splits the shards' records by image and orders every image's keys, boxes
-        and scores on the device; they come back with ONE copy and ONE event wait together with alive[B, L, T].
-        Grows the detection buffer and scans again if a shard overflowed.
-        Returns ([(keys uint64 [n_b], boxes float32 [n_b, 4], scores float32 [n_b]) per image], alive int64 [B, L, T])
-        -- views of the page-locked read-back buffer: copy what is kept -- or None when this form does not apply (a
-        pyramid beyond the sort key's bit fields, an image with more than _ORDER_ROWS detections): use fetch() then."""
+    def _order_buffers(self):
+        """Buffers of the batch's ordered read-back (scratch, output, its page-locked copy), on first use; whether the
+        form applies to this pyramid (the sort key's 10 / 14 / 14-bit fields)."""
         import torch
         p = self.plan
         if self._order is None:
             mu = max((int(lv["u"]) for lv in p.levels), default=0)
             mv = max((int(lv["v"]) for lv in p.levels), default=0)
             fits = 0 < p.n_levels <= 1024 and mu <= 16384 and mv <= 16384
-            self._order = dict(fits=fits, mu=mu, mv=mv)
+            od = self._order = dict(fits=fits, mu=mu, mv=mv)
             if fits:
                 P, B = self._ORDER_ROWS, self.batch
                 blk = 16 + 28 * P
-                od = self._order
                 od["scratch"] = torch.empty(B * (256 + 16 * P), dtype=torch.uint8, device=self.dev)
                 od["out"] = torch.empty(16 + B * blk, dtype=torch.uint8, device=self.dev)
                 od["h_out"] = torch.empty(16 + B * blk, dtype=torch.uint8).pin_memory()
+                od["ev"] = torch.cuda.Event()
                 h = od["h_out"].numpy()
                 od["info"] = h[:16].view(np.int32)
                 od["views"] = []
@@ -899,23 +894,45 @@ class PyramidEngine:
                                         h[o + 16 + 8 * P:o + 16 + 24 * P].view(np.float32).reshape(P, 4), h[o + 16 + 24 * P:o + blk].view(np.float32)))
                 if self._inv_scales_d is None:
                     self._inv_scales_d = torch.from_numpy(self.inv_scales()).to(self.dev)
-                self._fetch_ev = self._fetch_ev or torch.cuda.Event()
-        od = self._order
-        if not od["fits"]:
-            return None
+        return self._order["fits"]
+
+    def order_batch_enqueue(self, dm, stt):
+        """wb_det_order_batch_launch on the last scan's detections + the read-back copies (ordered results, alive[B, L, T])
+        into page-locked memory + an event, all in the current stream, no synchronisation: what fetch_ordered_batch
+        waits for.  Enqueued right behind the step, the results are on the host by the time they are asked for.
+        Returns False when the form does not apply to this pyramid."""
+        import torch
+        if not self._order_buffers():
+            return False
+        od, p = self._order, self.plan
+        if self._h_alive is None or self._h_alive.shape != stt["alive"].shape:
+            self._h_alive = torch.empty(stt["alive"].shape, dtype=torch.int32).pin_memory()
+        nat.check(self.lib.wb_det_order_batch_launch(nat.stream_ptr(), nat.ptr(self.detb.recs), nat.ptr(self.detb.counts),
+                                                     self.detb.cap, self.batch, nat.ptr(self._inv_scales_d), p.n_levels,
+                                                     od["mu"], od["mv"], dm.m, dm.n, nat.ptr(od["scratch"]),
+                                                     od["scratch"].numel(), nat.ptr(od["out"]), self._ORDER_ROWS),
+                  "wb_det_order_batch_launch")
+        od["h_out"].copy_(od["out"], non_blocking=True)
+        self._h_alive.copy_(stt["alive"], non_blocking=True)
+        od["ev"].record()
+        return True
+
+    def fetch_ordered_batch(self, dm, stt, enqueued=False):
+        """fetch() for a batch whose results are wanted image by image in the reference's order (Model.detect_stream's
+        batches): wb_det_order_batch_launch splits the shards' records by image and orders every image's keys, boxes
+        and scores on the device; they come back with ONE copy and ONE event wait together with alive[B, L, T].
+        enqueued: order_batch_enqueue has run behind the scan already (only the wait happens here).
+        Grows the detection buffer and scans again if a shard overflowed.
+        Returns ([(keys uint64 [n_b], boxes float32 [n_b, 4], scores float32 [n_b]) per image], alive int64 [B, L, T])
+        -- views of the page-locked read-back buffer: copy what is kept -- or None when this form does not apply (a
+        pyramid beyond the sort key's bit fields, an image with more than _ORDER_ROWS detections): use fetch() then."""
         T = dm.n_stages
         while True:
-            if self._h_alive is None or self._h_alive.shape != stt["alive"].shape:
-                self._h_alive = torch.empty(stt["alive"].shape, dtype=torch.int32).pin_memory()
-            nat.check(self.lib.wb_det_order_batch_launch(nat.stream_ptr(), nat.ptr(self.detb.recs), nat.ptr(self.detb.counts),
-                                                         self.detb.cap, self.batch, nat.ptr(self._inv_scales_d), p.n_levels,
-                                                         od["mu"], od["mv"], dm.m, dm.n, nat.ptr(od["scratch"]),
-                                                         od["scratch"].numel(), nat.ptr(od["out"]), self._ORDER_ROWS),
-                      "wb_det_order_batch_launch")
-            od["h_out"].copy_(od["out"], non_blocking=True)
-            self._h_alive.copy_(stt["alive"], non_blocking=True)
-            self._fetch_ev.record()
-            self._fetch_ev.synchronize()
+            if not enqueued and not self.order_batch_enqueue(dm, stt):
+                return None
+            enqueued = False
+            od = self._order
+            od["ev"].synchronize()
             worst = int(od["info"][1])
             if worst <= self.detb.cap:
                 break

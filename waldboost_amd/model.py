@@ -305,12 +305,15 @@ class Model:
                 out.set_field("scores", res["scores"])
                 return [out]
             with torch.cuda.stream(stream):
-                return self._collect_batch(eng, dm, token, count)
+                return self._collect_batch(eng, dm, token[0], count, enqueued=token[1])
 
         def send(f):
             _, eng, stream, dm, count = f
             with torch.cuda.stream(stream):
-                pending.append((eng, stream, dm, eng.batch_enqueue(dm), count))
+                stt = eng.batch_enqueue(dm)
+                # the batch's results split by image, ordered and on their way to the host right behind the scan
+                ordered = _ORDER_BATCH and eng.order_batch_enqueue(dm, stt)
+                pending.append((eng, stream, dm, (stt, ordered), count))
 
         try:
             for image in images:
@@ -368,7 +371,7 @@ class Model:
             if fill is not None:
                 fill[2].synchronize()
 
-    def _collect_batch(self, eng, dm, stt, count):
+    def _collect_batch(self, eng, dm, stt, count, enqueued=False):
         """Boxes of images [0, count) of the batch `eng` has just scanned (detect_stream; the slots behind `count` hold
         earlier images, whose results are dropped).  Split by image, ordered and finished on the device
         (wb_det_order_batch_launch) with one read-back; an image with more than 4096 detections sends the batch the
@@ -377,7 +380,8 @@ class Model:
         m, n, Cc = self.shape
         # split by image, ordered and finished on the device (wb_det_order_batch_launch: up to 4096 detections per
         # image): per image a copy of its slices of the one read-back
-        res = eng.fetch_ordered_batch(dm, stt) if _ORDER_BATCH else None   # ONE host synchronisation (overflow: grows and scans again)
+        # (enqueued: detect_stream has put the launch and the copies behind the scan already -- only the wait is left)
+        res = eng.fetch_ordered_batch(dm, stt, enqueued) if _ORDER_BATCH else None   # ONE host synchronisation (overflow: grows and scans again)
         if res is not None:
             per_image, alive = res
             self.n_loc += count * eng.plan.n_loc(m, n)
