@@ -532,7 +532,12 @@ def test_multi_model_detect_repeated_calls_replay_one_graph(dtype):
 
 
 # ------------------------------------------------------------------------------ batches / configs
-def test_detect_batch_equals_per_image_detect():
+@pytest.mark.parametrize("ordered_on_device", [True, False])
+def test_detect_batch_equals_per_image_detect(ordered_on_device, monkeypatch):
+    """ordered_on_device: the batch's results split by image and ordered by wb_det_order_batch_launch (one read-back);
+    False: the form it falls back to (device sort of all records, wb_boxes_launch)."""
+    import waldboost_amd.model as wm
+    monkeypatch.setattr(wm, "_ORDER_BATCH", ordered_on_device)
     imgs = np.stack([synth_image(210, 290, 600 + b) for b in range(5)])
     M = random_model(42, 30, 2)
     per = []

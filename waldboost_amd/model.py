@@ -452,6 +452,20 @@ class Model:
                         alive=np.zeros((B, 0, T), np.int64), scales=[])
         eng.load_images(images)
         stt = eng.run(dm)
+        # split by image, ordered and finished on the device, one read-back (up to 4096 detections per image and 256
+        # images: the read-back block is fixed-size); otherwise a device sort of all records and wb_boxes_launch
+        res = eng.fetch_ordered_batch(dm, stt) if (_ORDER_BATCH and B <= 256) else None
+        if res is not None:
+            per_image, alive = res
+            alive = alive.reshape(B, L, T)
+            self.n_loc += B * eng.plan.n_loc(m, n)
+            self.n_weak += int(alive.sum())
+            keys = np.concatenate([k for k, _, _ in per_image]) if B else np.empty(0, np.uint64)
+            return dict(batch=B, image=np.repeat(np.arange(B, dtype=np.int32), [k.size for k, _, _ in per_image]),
+                        level=(keys >> np.uint64(54)).astype(np.int32), r=((keys >> np.uint64(40)) & np.uint64(0x3fff)).astype(np.int64),
+                        c=((keys >> np.uint64(26)) & np.uint64(0x3fff)).astype(np.int64),
+                        boxes=np.concatenate([b_ for _, b_, _ in per_image]), scores=np.concatenate([s_ for _, _, s_ in per_image]),
+                        alive=alive, scales=list(eng.plan.scales))
         eng.ensure_capacity(dm)
         det = eng.sorted_detections()
         boxes, scores = eng.boxes(det, dm)
