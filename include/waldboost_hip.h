@@ -345,11 +345,14 @@ int wb_det_finish_launch(void *stream, const WbDet *det, const uint32_t *det_cou
  * min(out_capacity, 4096) the three sections are written IN KEY ORDER -- keys[i] ascending, boxes[i] / scores[i] the
  * i-th detection of the reference's order (a key's low 26 bits then name the packed position the record came from and
  * carry no meaning for the caller) -- and header[3] = 1.  Otherwise header[3] = 0 and the sections are exactly what
- * wb_det_finish_launch writes (sort the keys, gather).  header[0..2] as wb_det_pack_launch writes them.  One workgroup;
- * no host synchronisation. */
+ * wb_det_finish_launch writes (sort the keys, gather).  header[0..2] as wb_det_pack_launch writes them.
+ *   tail, tail_words  optional (NULL, 0): dev int32 words copied behind the scores section, out + 16 + 28 * out_capacity
+ *                     bytes -- the scan's alive[] statistics (model.py:248,252), so that ONE read-back carries all a
+ *                     Model.detect call returns
+ * No host synchronisation. */
 int wb_det_finish_sorted_launch(void *stream, const WbDet *det, const uint32_t *det_count, uint32_t shard_capacity,
                                 const float *inv_scale, int n_levels, int max_rows, int max_cols, int m, int n,
-                                void *out, uint32_t out_capacity);
+                                void *out, uint32_t out_capacity, const int32_t *tail, uint32_t tail_words);
 
 /* The same for a BATCH (the reference's detection loop over files, scripts/waldboost-detect.py:64-67, taken a batch at a
  * time): the shards' records are first split by image into buckets (scratch), then every image's bucket is ordered and

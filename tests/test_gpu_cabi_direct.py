@@ -165,7 +165,7 @@ def test_pyramid_and_cascade_through_the_raw_abi():
     dims = (C.c_int(plan.n_levels), C.c_int(max(int(lv["u"]) for lv in plan.levels)), C.c_int(max(int(lv["v"]) for lv in plan.levels)),
             C.c_int(12), C.c_int(12))
     _check(lib, lib.wb_det_finish_sorted_launch(st, P(det2[16:].data_ptr()), P(det2.data_ptr()), C.c_uint32(cap), P(inv.data_ptr()),
-                                                *dims, P(fin2.data_ptr()), C.c_uint32(Pn)))
+                                                *dims, P(fin2.data_ptr()), C.c_uint32(Pn), None, C.c_uint32(0)))
     torch.cuda.synchronize()
     f2 = fin2.cpu().numpy()
     assert f2[:16].view(np.int32).tolist() == [d.size, int(det2[:16].max()), d.size, 0]
@@ -182,7 +182,7 @@ def test_pyramid_and_cascade_through_the_raw_abi():
     few[16:] = torch.from_numpy(body.reshape(-1, 4)).to(dev)
     fin3 = torch.zeros(16 + 28 * 4096, dtype=torch.uint8, device=dev)
     _check(lib, lib.wb_det_finish_sorted_launch(st, P(few[16:].data_ptr()), P(few.data_ptr()), C.c_uint32(64), P(inv.data_ptr()),
-                                                *dims, P(fin3.data_ptr()), C.c_uint32(4096)))
+                                                *dims, P(fin3.data_ptr()), C.c_uint32(4096), None, C.c_uint32(0)))
     torch.cuda.synchronize()
     f3 = fin3.cpu().numpy()
     assert f3[:16].view(np.int32).tolist() == [keep.size, int(cnt.max()), keep.size, 1]

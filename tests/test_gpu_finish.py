@@ -15,7 +15,7 @@ P = C.c_void_p
 SHARDS = 64
 
 
-def _finish(lib, fn, recs_by_shard, cap, inv, m, n, out_cap, n_levels=40, mr=16384, mc=16384):
+def _finish(lib, fn, recs_by_shard, cap, inv, m, n, out_cap, n_levels=40, mr=16384, mc=16384, tail=None):
     import torch
     from waldboost_amd import _native as nat
     dev = "cuda:0"
@@ -27,14 +27,21 @@ def _finish(lib, fn, recs_by_shard, cap, inv, m, n, out_cap, n_levels=40, mr=163
     det_d = torch.from_numpy(det).to(dev)
     cnt_d = torch.from_numpy(counts.view(np.int32)).to(dev)
     inv_d = torch.from_numpy(inv).to(dev)
-    out = torch.full((16 + 28 * out_cap,), 0xCD, dtype=torch.uint8, device=dev)
+    n_tail = 0 if tail is None else tail.size
+    out = torch.full((16 + 28 * out_cap + 4 * n_tail,), 0xCD, dtype=torch.uint8, device=dev)
+    more = ()
+    if fn is lib.wb_det_finish_sorted_launch:                # (takes the caller's tail words: the scan's statistics)
+        tail_d = None if tail is None else torch.from_numpy(tail).to(dev)
+        more = (None if tail is None else P(tail_d.data_ptr()), C.c_uint32(n_tail))
     rc = fn(None, P(det_d.data_ptr()), P(cnt_d.data_ptr()), C.c_uint32(cap), P(inv_d.data_ptr()), C.c_int(n_levels), C.c_int(mr),
-            C.c_int(mc), C.c_int(m), C.c_int(n), P(out.data_ptr()), C.c_uint32(out_cap))
+            C.c_int(mc), C.c_int(m), C.c_int(n), P(out.data_ptr()), C.c_uint32(out_cap), *more)
     assert rc == 0, lib.wb_last_error()
     torch.cuda.synchronize()
     h = out.cpu().numpy()
+    if tail is not None:
+        assert np.array_equal(h[16 + 28 * out_cap:].view(np.int32), tail)
     return (h[:16].view(np.int32), h[16:16 + 8 * out_cap].view(np.uint64), h[16 + 8 * out_cap:16 + 24 * out_cap].view(np.float32).reshape(-1, 4),
-            h[16 + 24 * out_cap:].view(np.float32))
+            h[16 + 24 * out_cap:16 + 28 * out_cap].view(np.float32))
 
 
 def _records(rng, total, n_levels=40):
@@ -60,7 +67,8 @@ def test_finish_sorted_orders_keys_boxes_and_scores(total):
     inv = (1.0 / (1.0 + 0.09 * np.arange(40))).astype(np.float32)
     m, n = 12, 14
     out_cap = 4096
-    hdr, keys, boxes, scores = _finish(lib, lib.wb_det_finish_sorted_launch, by, cap, inv, m, n, out_cap)
+    tail = rng.integers(-5, 1 << 30, size=(total * 7) % 9001, dtype=np.int32) if total % 3 else None   # (alive[] in Model.detect)
+    hdr, keys, boxes, scores = _finish(lib, lib.wb_det_finish_sorted_launch, by, cap, inv, m, n, out_cap, tail=tail)
     assert hdr.tolist() == [total, max(len(b) for b in by) if total else 0, total, 1]
     order = np.lexsort((d["c"], d["r"], d["level"]))
     e = d[order]
@@ -88,7 +96,7 @@ def test_finish_sorted_leaves_large_results_to_the_host(total, out_cap):
     by = [d[shard == s] for s in range(SHARDS)]
     cap = max(len(b) for b in by)
     inv = (1.0 / (1.0 + 0.09 * np.arange(40))).astype(np.float32)
-    a = _finish(lib, lib.wb_det_finish_sorted_launch, by, cap, inv, 12, 12, out_cap)
+    a = _finish(lib, lib.wb_det_finish_sorted_launch, by, cap, inv, 12, 12, out_cap, tail=np.arange(777, dtype=np.int32))
     b = _finish(lib, lib.wb_det_finish_launch, by, cap, inv, 12, 12, out_cap)
     present = min(total, out_cap)
     assert a[0].tolist() == [total, cap, present, 0] and b[0].tolist() == [total, cap, present, cap]

@@ -76,7 +76,8 @@ SYMBOLS = {
     "wb_boxes_launch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int, C.c_int, _P, _P]),
     "wb_det_pack_launch": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32]),
     "wb_det_finish_launch": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_uint32]),
-    "wb_det_finish_sorted_launch": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_uint32]),
+    "wb_det_finish_sorted_launch": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_uint32, _P,
+                                              C.c_uint32]),
     "wb_det_order_batch_launch": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t,
                                             _P, C.c_uint32]),
     "wb_selftest_projection": (C.c_int, [_P, _P]),

@@ -331,15 +331,19 @@ __global__ __launch_bounds__(256) void det_finish_kernel(const WbDet *det, const
 // (img_det / img_out: their distances in records / int32 words); a single image launches one row.
 __global__ __launch_bounds__(256) void det_finish_sorted_kernel(const WbDet *det, const uint32_t *det_count, uint32_t cap,
                                                                  const float *inv_scale, int m, int n, int32_t *out, uint32_t out_cap,
-                                                                 size_t img_det, size_t img_out) {
+                                                                 size_t img_det, size_t img_out, const int32_t *tail, uint32_t tail_words) {
     static_assert(WB_DET_SHARDS == 64, "one counter per lane of a wave, one workgroup per shard");
     __shared__ unsigned long long skey[WB_FINISH_SORT_MAX];
+    __shared__ float sscore[WB_FINISH_SORT_MAX];
     __shared__ uint32_t sbefore[65];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wg = blockIdx.x;
     det_count += (size_t)blockIdx.y * WB_DET_SHARDS;
     det += (size_t)blockIdx.y * img_det;
     out += (size_t)blockIdx.y * img_out;
+    // the caller's tail words (the scan's alive[] statistics) behind the scores: ONE read-back carries everything
+    if (tail != nullptr)
+        for (uint32_t i = (uint32_t)wg * 256u + (uint32_t)tid; i < tail_words; i += gridDim.x * 256u) out[4 + 7 * (size_t)out_cap + i] = tail[i];
     const uint32_t raw = det_count[lane];
     const uint32_t mine = raw < cap ? raw : cap;
     uint32_t before = 0, total = 0, worst = 0;                // before: valid records in the shards in front of shard `lane`
@@ -399,22 +403,21 @@ __global__ __launch_bounds__(256) void det_finish_sorted_kernel(const WbDet *det
     // all keys into LDS: WB_FINISH_SORT_MAX / 256 records per thread, every load requested before the first is used
     constexpr int PER = WB_FINISH_SORT_MAX / 256;
     {
-        uint2 lr[PER];                                        // (level, r | c << 16): the words of a record that make its key
+        uint4 lr[PER];                                        // (image, level, r | c << 16, score)
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const uint32_t q = (uint32_t)tid + 256u * k;
-            lr[k] = make_uint2(0u, 0u);
-            if (q < total) {
-                const uint32_t *w = reinterpret_cast<const uint32_t *>(locate(q));
-                lr[k] = make_uint2(w[1], w[2]);
-            }
+            lr[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (q < total) lr[k] = *reinterpret_cast<const uint4 *>(locate(q));
         }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const uint32_t q = (uint32_t)tid + 256u * k;
-            if (q < total)
-                skey[q] = ((unsigned long long)lr[k].x << 54) | ((unsigned long long)(lr[k].y & 0xffffu) << 40) |
-                          ((unsigned long long)(lr[k].y >> 16) << 26) | (unsigned long long)q;
+            if (q < total) {
+                skey[q] = ((unsigned long long)lr[k].y << 54) | ((unsigned long long)(lr[k].z & 0xffffu) << 40) |
+                          ((unsigned long long)(lr[k].z >> 16) << 26) | (unsigned long long)q;
+                sscore[q] = __uint_as_float(lr[k].w);        // (the record's second visit below needs no memory)
+            }
         }
     }
     __syncthreads();
@@ -437,10 +440,9 @@ __global__ __launch_bounds__(256) void det_finish_sorted_kernel(const WbDet *det
 #pragma unroll
     for (uint32_t d = 1; d < TPR; d <<= 1) smaller += (uint32_t)__shfl_xor((int)smaller, (int)d);
     if (live && part == 0) {
-        const WbDet d = *locate(q);
         keys[smaller] = me;
-        boxes[smaller] = box_of((uint32_t)d.level, d.r, d.c);
-        scores[smaller] = d.score;
+        boxes[smaller] = box_of((uint32_t)(me >> 54), (uint32_t)(me >> 40) & 0x3fffu, (uint32_t)(me >> 26) & 0x3fffu);
+        scores[smaller] = sscore[q];
     }
 }
 
@@ -773,7 +775,8 @@ extern "C" int wb_det_finish_launch(void *stream, const WbDet *det, const uint32
 
 extern "C" int wb_det_finish_sorted_launch(void *stream, const WbDet *det, const uint32_t *det_count, uint32_t shard_capacity,
                                            const float *inv_scale, int n_levels, int max_rows, int max_cols, int m, int n,
-                                           void *out, uint32_t out_capacity) {
+                                           void *out, uint32_t out_capacity, const int32_t *tail, uint32_t tail_words) {
+    WB_REQUIRE(tail || tail_words == 0, "wb_det_finish_sorted_launch: tail is null but tail_words > 0");
     WB_REQUIRE(det_count && out && inv_scale, "wb_det_finish_sorted_launch: null pointer");
     WB_REQUIRE(det || shard_capacity == 0, "wb_det_finish_sorted_launch: det is null but capacity > 0");
     WB_REQUIRE(reinterpret_cast<uintptr_t>(out) % 16 == 0, "wb_det_finish_sorted_launch: out must be 16-byte aligned");
@@ -785,7 +788,7 @@ extern "C" int wb_det_finish_sorted_launch(void *stream, const WbDet *det, const
     }
     static_assert(WB_FINISH_GRID >= WB_DET_SHARDS, "a workgroup per shard for the unordered form");
     hipLaunchKernelGGL(det_finish_sorted_kernel, dim3(WB_FINISH_GRID), dim3(256), 0, (hipStream_t)stream, det, det_count,
-                       shard_capacity, inv_scale, m, n, reinterpret_cast<int32_t *>(out), out_capacity, (size_t)0, (size_t)0);
+                       shard_capacity, inv_scale, m, n, reinterpret_cast<int32_t *>(out), out_capacity, (size_t)0, (size_t)0, tail, tail_words);
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;
 }
@@ -816,7 +819,8 @@ extern "C" int wb_det_order_batch_launch(void *stream, const WbDet *det, const u
     hipLaunchKernelGGL(det_bucket_kernel, dim3(n_images), dim3(1024), 0, (hipStream_t)stream, det, det_count, shard_capacity, bucket,
                        out_capacity, bucket_count, info);
     hipLaunchKernelGGL(det_finish_sorted_kernel, dim3(WB_FINISH_GRID, n_images), dim3(256), 0, (hipStream_t)stream, bucket, bucket_count,
-                       out_capacity, inv_scale, m, n, info + 4, out_capacity, (size_t)out_capacity, (size_t)(4 + 7 * (size_t)out_capacity));
+                       out_capacity, inv_scale, m, n, info + 4, out_capacity, (size_t)out_capacity, (size_t)(4 + 7 * (size_t)out_capacity),
+                       (const int32_t *)nullptr, 0u);
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;
 }

@@ -807,27 +807,31 @@ class PyramidEngine:
         return True
 
     def _final_enqueue(self, dm, stt):
-        """wb_det_finish_sorted_launch + the two read-back copies into page-locked memory (no synchronisation).  The buffers
+        """wb_det_finish_sorted_launch + the ONE read-back copy into page-locked memory (no synchronisation).  The buffers
         belong to the cascade's scan state: several cascades can be scanned back to back on one engine (waldboost.detect)
         and read back with ONE wait -- the shared detection buffer is free again as soon as this launch has run."""
         import torch
-        if "final" not in stt:
+        n_alive = stt["alive"].numel()
+        if "final" not in stt or stt["final_alive_words"] != n_alive:
+            # header | keys | boxes | scores | alive[B, L, T] (the kernel copies the statistics behind the scores: one
+            # read-back copy instead of two)
             P = self._FETCH_ROWS
-            nbytes = 16 + P * 28
+            nbytes = 16 + P * 28 + 4 * n_alive
             stt["final"] = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
             stt["h_final"] = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+            stt["final_alive_words"] = n_alive
             h = stt["h_final"].numpy()
             stt["h_final_views"] = (h[:16].view(np.int32), h[16:16 + 8 * P].view(np.uint64),
-                                    h[16 + 8 * P:16 + 24 * P].view(np.float32).reshape(P, 4), h[16 + 24 * P:].view(np.float32))
-            stt["h_alive"] = torch.empty(stt["alive"].shape, dtype=torch.int32).pin_memory()
+                                    h[16 + 8 * P:16 + 24 * P].view(np.float32).reshape(P, 4), h[16 + 24 * P:16 + 28 * P].view(np.float32))
+            stt["h_alive"] = h[16 + 28 * P:].view(np.int32).reshape(tuple(stt["alive"].shape))
         # (ordered on the device: one workgroup sorts the keys in LDS and writes keys, boxes and scores in the reference's
         # order whenever they number at most 4096 -- header[3] says whether it did)
         nat.check(self.lib.wb_det_finish_sorted_launch(nat.stream_ptr(), nat.ptr(self.detb.recs), nat.ptr(self.detb.counts),
                                                        self.detb.cap, nat.ptr(self._inv_scales_d), self.plan.n_levels,
                                                        self._final_dims[1], self._final_dims[2], dm.m, dm.n,
-                                                       nat.ptr(stt["final"]), self._FETCH_ROWS), "wb_det_finish_sorted_launch")
+                                                       nat.ptr(stt["final"]), self._FETCH_ROWS, nat.ptr(stt["alive"]), n_alive),
+                  "wb_det_finish_sorted_launch")
         stt["h_final"].copy_(stt["final"], non_blocking=True)
-        stt["h_alive"].copy_(stt["alive"], non_blocking=True)
 
     def fetch_final(self, dm, stt, enqueued=False, stream=None):
         """fetch() for Model.detect on ONE image: wb_det_finish_launch leaves sort keys, boxes and scores of all
@@ -863,7 +867,7 @@ class PyramidEngine:
             stt = self.run_cascade(dm, ranks=stt.get("ranks", False))
         if total > P:
             return None
-        alive = stt["h_alive"].numpy()[:, :, :T].astype(np.int64)
+        alive = stt["h_alive"][:, :, :T].astype(np.int64)
         return keys[:total], boxes, scores, alive, bool(hdr[3])
 
     _ORDER_ROWS = 4096               # per image: what wb_det_order_batch_launch orders (more: the caller's other path)
@@ -949,7 +953,7 @@ class PyramidEngine:
 
     def detect_run(self, dm):
         """Model.detect's whole device sequence for the resident image -- one memset, octaves, channels, cascade,
-        wb_det_finish_launch, the two read-back copies -- and its one synchronisation; from the second call with the
+        wb_det_finish_sorted_launch (which also carries alive[] behind the scores), the ONE read-back copy -- and its one synchronisation; from the second call with the
         same cascade on it is replayed as ONE hipGraph (one enqueue instead of seven, no gaps between the kernels).
         Returns what fetch_final returns, or None (then: run(dm) has happened, use fetch())."""
         return self.detect_collect(dm, self.detect_enqueue(dm))
@@ -1004,7 +1008,7 @@ class PyramidEngine:
     def detect_multi_run(self, dms, ranks):
         """waldboost.detect's whole device sequence for the resident image -- octaves, ONE channel pyramid (as ranks of
         dms[0]'s rank tables -- a rank group's union tables -- or as float32 channels), then per cascade of `dms` its
-        scan, wb_det_finish_launch and the read-back copies -- with ONE wait at its end; from the second call with the
+        scan, wb_det_finish_sorted_launch and the read-back copy -- with ONE wait at its end; from the second call with the
         same cascades on it is one hipGraph replay.  Returns [what fetch_final returns, per cascade], or None when that
         form does not apply (more cascades than an engine keeps states for, a pyramid beyond the sort key's fields, an
         overflowing detection buffer, more detections than one read-back holds): the caller then scans model by model."""
@@ -1055,7 +1059,7 @@ class PyramidEngine:
                 st["fails"] += 1                              # (tried again after 16, 32, 64 ... calls)
                 st["skip"] = min(8 << st["fails"], 4096)
                 return None
-            out.append((keys[:total], boxes, scores, stt["h_alive"].numpy()[:, :, :d.n_stages].astype(np.int64), bool(hdr[3])))
+            out.append((keys[:total], boxes, scores, stt["h_alive"][:, :, :d.n_stages].astype(np.int64), bool(hdr[3])))
         st["fails"] = 0
         return out
 
