@@ -316,19 +316,20 @@ __global__ __launch_bounds__(256) void det_finish_kernel(const WbDet *det, const
 // det_finish_kernel with the ordering done here as well (wb_det_finish_sorted_launch).  The keys are unique, so a record's
 // place in the reference's order is the NUMBER OF SMALLER KEYS: every workgroup gathers all n <= WB_FINISH_SORT_MAX keys
 // into LDS (50 KB of L2 reads, every load in flight at once: a thread finds the shard of its flat index by bisection of
-// the shards' prefix sums), ranks its own 32 records against them -- eight threads per record, each over an eighth of
-// the keys, the keys as LDS broadcast reads -- and writes key, box and score straight to the record's rank: up to 128
-// workgroups of 32 records on as many CUs.  (One workgroup sorting in LDS -- a bitonic network, built first --
+// the shards' prefix sums), ranks its own 16 records against them -- sixteen threads per record, each over a sixteenth of
+// the keys, the keys as LDS broadcast reads -- and writes key, box and score straight to the record's rank: up to 256
+// workgroups of 16 records, one per CU.  (One workgroup sorting in LDS -- a bitonic network, built first --
 // took 37 us for the same: 78 stages x 64 KB through ONE CU's LDS.)  The host takes slices instead of sorting and
 // gathering (0.03 ms of a 0.23 ms Model.detect call, and the step that bounded Model.detect_stream at batch 1).
 // header[3] = 1 says so.  More valid records than WB_FINISH_SORT_MAX (or than out_cap): the sections are written
 // unordered, exactly as det_finish_kernel leaves them, header[3] = 0.
 #define WB_FINISH_SORT_MAX 4096
-#define WB_FINISH_TPR 8                                        // threads per record
-#define WB_FINISH_RPW (256 / WB_FINISH_TPR)                    // records per workgroup
-#define WB_FINISH_GRID (WB_FINISH_SORT_MAX / WB_FINISH_RPW)    // >= WB_DET_SHARDS: the unordered form wants a workgroup per shard
+// TPR threads per record, 256 / TPR records per workgroup, WB_FINISH_SORT_MAX * TPR / 256 workgroups (>= WB_DET_SHARDS: the
+// unordered form wants a workgroup per shard).  One image: TPR = 16, 256 workgroups -- the latency of Model.detect's last
+// step; a batch: TPR = 4, 64 workgroups per image (every workgroup gathers all of its image's keys: fewer, longer ones).
 // blockIdx.y: the image of a batch (wb_det_order_batch_launch) -- its own 64 counters, record region and output block
 // (img_det / img_out: their distances in records / int32 words); a single image launches one row.
+template <int TPR>
 __global__ __launch_bounds__(256) void det_finish_sorted_kernel(const WbDet *det, const uint32_t *det_count, uint32_t cap,
                                                                  const float *inv_scale, int m, int n, int32_t *out, uint32_t out_cap,
                                                                  size_t img_det, size_t img_out, const int32_t *tail, uint32_t tail_words) {
@@ -387,7 +388,8 @@ __global__ __launch_bounds__(256) void det_finish_sorted_kernel(const WbDet *det
         }
         return;
     }
-    if (total <= (uint32_t)(WB_FINISH_RPW * wg)) return;      // (this workgroup's records start behind the last one)
+    constexpr int RPW = 256 / TPR;
+    if (total <= (uint32_t)(RPW * wg)) return;                // (this workgroup's records start behind the last one)
     if (tid < 64) sbefore[tid] = before;
     if (tid == 0) sbefore[64] = total;
     __syncthreads();
@@ -406,9 +408,10 @@ __global__ __launch_bounds__(256) void det_finish_sorted_kernel(const WbDet *det
         uint4 lr[PER];                                        // (image, level, r | c << 16, score)
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
+            // (unconditional: positions past the end load the last record again -- with a branch around it every
+            // bisection, six dependent LDS reads, ran alone: sixteen of them in a row were a quarter of the kernel)
             const uint32_t q = (uint32_t)tid + 256u * k;
-            lr[k] = make_uint4(0u, 0u, 0u, 0u);
-            if (q < total) lr[k] = *reinterpret_cast<const uint4 *>(locate(q));
+            lr[k] = *reinterpret_cast<const uint4 *>(locate(q < total ? q : total - 1u));
         }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -423,8 +426,8 @@ __global__ __launch_bounds__(256) void det_finish_sorted_kernel(const WbDet *det
     __syncthreads();
     // TPR threads per record, each over the keys j = part, part + TPR, ... (a wave's records read the same TPR keys at a
     // time: LDS broadcasts), eight keys per thread and pass in flight
-    constexpr uint32_t TPR = WB_FINISH_TPR, UN = 8;
-    const uint32_t q = (uint32_t)(WB_FINISH_RPW * wg) + (uint32_t)tid / TPR, part = (uint32_t)tid % TPR;
+    constexpr uint32_t UN = 8;
+    const uint32_t q = (uint32_t)(RPW * wg) + (uint32_t)tid / TPR, part = (uint32_t)tid % TPR;
     const bool live = q < total;
     const unsigned long long me = skey[live ? q : 0u];
     uint32_t smaller = 0;
@@ -786,8 +789,7 @@ extern "C" int wb_det_finish_sorted_launch(void *stream, const WbDet *det, const
                      n_levels, max_rows, max_cols, out_capacity);
         return WB_ERR_UNSUPPORTED;
     }
-    static_assert(WB_FINISH_GRID >= WB_DET_SHARDS, "a workgroup per shard for the unordered form");
-    hipLaunchKernelGGL(det_finish_sorted_kernel, dim3(WB_FINISH_GRID), dim3(256), 0, (hipStream_t)stream, det, det_count,
+    hipLaunchKernelGGL(det_finish_sorted_kernel<16>, dim3(WB_FINISH_SORT_MAX * 16 / 256), dim3(256), 0, (hipStream_t)stream, det, det_count,
                        shard_capacity, inv_scale, m, n, reinterpret_cast<int32_t *>(out), out_capacity, (size_t)0, (size_t)0, tail, tail_words);
     WB_HIP_CHECK(hipGetLastError());
     return WB_OK;
@@ -818,7 +820,8 @@ extern "C" int wb_det_order_batch_launch(void *stream, const WbDet *det, const u
     int32_t *info = reinterpret_cast<int32_t *>(out);
     hipLaunchKernelGGL(det_bucket_kernel, dim3(n_images), dim3(1024), 0, (hipStream_t)stream, det, det_count, shard_capacity, bucket,
                        out_capacity, bucket_count, info);
-    hipLaunchKernelGGL(det_finish_sorted_kernel, dim3(WB_FINISH_GRID, n_images), dim3(256), 0, (hipStream_t)stream, bucket, bucket_count,
+    static_assert(WB_FINISH_SORT_MAX * 4 / 256 >= WB_DET_SHARDS, "a workgroup per shard for the unordered form");
+    hipLaunchKernelGGL(det_finish_sorted_kernel<4>, dim3(WB_FINISH_SORT_MAX * 4 / 256, n_images), dim3(256), 0, (hipStream_t)stream, bucket, bucket_count,
                        out_capacity, inv_scale, m, n, info + 4, out_capacity, (size_t)out_capacity, (size_t)(4 + 7 * (size_t)out_capacity),
                        (const int32_t *)nullptr, 0u);
     WB_HIP_CHECK(hipGetLastError());
