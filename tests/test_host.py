@@ -354,3 +354,28 @@ def test_model_copies_and_pickles_without_its_device_state():
         assert len(N) == len(M) and tuple(N.shape) == tuple(M.shape) and "_lanes" not in N.__dict__ and N._device is None
         for (w, t), (v, u) in zip(M, N):
             assert t == u and all(np.array_equal(getattr(w, k), getattr(v, k)) for k in ("feature", "threshold", "left", "right", "prediction"))
+
+
+def test_tile_lists_dispatch_the_short_workgroups_last_on_every_xcd():
+    """plan._tiles: the same tiles as the natural order; on every XCD (dispatch slots x, x + 8, ...) the tiles known to be
+    short -- the channel kernel's identity levels and bottom-cut tiles, the cascade's edge-cut tiles -- come behind all
+    others, costliest first; a plan with short_last off (large batches, WB_TILE_ORDER=natural) keeps the plain order."""
+    for args in [(1080, 1920, 2, 8, 1), (300, 500, 2, 4, 1), (64, 64, 2, 8, 1)]:
+        p, q = PyramidPlan(*args), PyramidPlan(*args)
+        q.short_last = False
+        assert p.short_last
+        tc, tc0 = p.chan_tiles(), q.chan_tiles()
+        tk, tk0 = p.casc_tiles(12, 12, 32, 64), q.casc_tiles(12, 12, 32, 64)
+        assert sorted(map(tuple, tc.tolist())) == sorted(map(tuple, tc0.tolist()))
+        assert sorted(map(tuple, tk.tolist())) == sorted(map(tuple, tk0.tolist()))
+        grid = p.window_grid(12, 12)
+        full = np.array([min(32, grid[t["level"]][0] - t["ty"] * 32) == 32 and min(64, grid[t["level"]][1] - t["tx"] * 64) == 64 for t in tk])
+        ident = np.array([p.levels[t["level"]]["h"] == p.levels[t["level"]]["nh"] and p.levels[t["level"]]["w"] == p.levels[t["level"]]["nw"]
+                          for t in tc])
+        for x in range(8):
+            f = full[x::8]
+            if f.any() and not f.all():
+                assert f[:int(f.sum())].all()                 # every full cascade tile of this XCD in front of its cut ones
+            i = ident[x::8]
+            if i.any():
+                assert not i[:int(np.argmax(i))].any() and i.sum() <= i.size - np.argmax(i)   # no identity tile before the first short one

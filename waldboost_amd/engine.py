@@ -365,6 +365,8 @@ class PyramidEngine:
                                 n_chn=self.spec.n_channels, chn_bytes=self.spec.dtype.itemsize, chan_func=self.spec.func_id)
         self.exact_single = exact_single
         p = self.plan
+        # (tile lists with the short workgroups last: for one or two images per launch -- plan._tiles)
+        p.short_last = p.short_last and self.batch <= 2
         dev = self.dev
         # flat allocations with 16 spare elements: the channel kernel fetches source rows with
         # 4-byte-aligned dword loads that may touch a few bytes past the last row

@@ -14,6 +14,8 @@ HBM layout per image (one contiguous buffer each, images of a batch at a fixed s
 """
 import math
 
+import os
+
 import numpy as np
 
 from ._native import LEVEL_DTYPE, TAP_DTYPE, TILE_DTYPE
@@ -91,6 +93,10 @@ class PyramidPlan:
 
         self._table = None
         self._chan_tiles = None
+        # tile lists with the workgroups known to be short dispatched last on every XCD (_tiles): the engine keeps it for
+        # batches of one or two images -- with more, a launch is image after image of the same list and only its very end
+        # has a tail -- and WB_TILE_ORDER=natural switches it off (A/B runs)
+        self.short_last = os.environ.get("WB_TILE_ORDER", "") != "natural"
 
     # ------------------------------------------------------------------ layout
     def chn_offsets(self):
@@ -151,8 +157,13 @@ class PyramidPlan:
 
     # ------------------------------------------------------------------ tiles
     @staticmethod
-    def _tiles(dims, tr, tc):
-        """dims: per level (rows, cols) to cover with tr x tc tiles; natural order, XCD-permuted."""
+    def _tiles(dims, tr, tc, cheap=None):
+        """dims: per level (rows, cols) to cover with tr x tc tiles; natural order, XCD-permuted.
+        cheap: callable(tiles in natural order) -> (bool mask of the tiles known to be SHORT workgroups -- the channel
+        kernel's identity levels (a copy instead of a resample), tiles cut by the edge of their level --, their relative
+        cost).  Every XCD is handed its share of them, costliest first, behind its share of the others: the workgroups
+        that start last are the short ones (a kernel ends one workgroup lifetime after its last dispatch, and in a
+        pipeline of several streams the next kernel's workgroups move into slots that free up one by one)."""
         parts = []
         for l, (r, c) in enumerate(dims):
             if r <= 0 or c <= 0:
@@ -165,6 +176,28 @@ class PyramidPlan:
         if not parts:
             return np.zeros(0, TILE_DTYPE)
         nat = np.concatenate(parts)
+        if cheap is not None:
+            mask, cost = cheap(nat)
+            a, b = nat[~mask], nat[mask]
+            b = b[np.argsort(-cost[mask], kind="stable")]
+            n = nat.size
+            slots = [len(range(x, n, 8)) for x in range(8)]
+            ia = np.array_split(np.arange(a.size), 8)
+            if a.size and b.size and all(len(ia[x]) <= slots[x] for x in range(8)):
+                # XCD x runs dispatch slots x, x + 8, ...: its share of `a` (a contiguous run of the natural order, as
+                # xcd_order deals them), then every eighth tile of `b` (costliest first on every XCD)
+                out = np.zeros(n, TILE_DTYPE)
+                need = [slots[x] - len(ia[x]) for x in range(8)]
+                ib = [[] for _ in range(8)]
+                x = 0
+                for j in range(b.size):                      # deal b round-robin over the XCDs that still have room
+                    while len(ib[x]) >= need[x]:
+                        x = (x + 1) % 8
+                    ib[x].append(j)
+                    x = (x + 1) % 8
+                for x in range(8):
+                    out[x::8] = np.concatenate([a[ia[x]], b[np.asarray(ib[x], dtype=np.intp)]])
+                return out
         return nat[xcd_order(nat.size)]
 
     @staticmethod
@@ -180,7 +213,19 @@ class PyramidPlan:
     def chan_tiles(self):
         if self._chan_tiles is None:
             tu, tv = chan_tile(self.chan_func, self.shrink)
-            self._chan_tiles = self._tiles([(lv["u"], lv["v"]) for lv in self.levels], tu, tv)
+            cheap = None
+            if self.short_last:
+                # the channel kernel's short workgroups: tiles of identity levels (level = its octave's own size: a copy
+                # instead of a resample, 8 against 12.5 ns per tile) and tiles cut by the bottom edge of their level (the
+                # kernel computes only the rows they hold)
+                ident = np.array([lv["h"] == lv["nh"] and lv["w"] == lv["nw"] for lv in self.levels], bool)
+                us = np.array([lv["u"] for lv in self.levels], np.int64)
+
+                def cheap(nat):
+                    rows = np.minimum(tu, us[nat["level"]] - nat["ty"].astype(np.int64) * tu)   # output rows the tile holds
+                    cost = np.where(ident[nat["level"]], 0.65, 1.0) * (0.35 + 0.65 * rows / tu)
+                    return ident[nat["level"]] | (rows < tu), cost
+            self._chan_tiles = self._tiles([(lv["u"], lv["v"]) for lv in self.levels], tu, tv, cheap=cheap)
         return self._chan_tiles
 
     def window_grid(self, m, n):
@@ -189,7 +234,18 @@ class PyramidPlan:
         return [(max(lv["u"] - m, 0), max(lv["v"] - n, 0)) for lv in self.levels]
 
     def casc_tiles(self, m, n, tile_rows, tile_cols):
-        return self._tiles(self.window_grid(m, n), tile_rows, tile_cols)
+        grid = self.window_grid(m, n)
+        cheap = None
+        if self.short_last:                                   # the cascade's short workgroups: tiles cut by an edge of their level
+            nr = np.array([g[0] for g in grid], np.int64)
+            nc = np.array([g[1] for g in grid], np.int64)
+
+            def cheap(nat):
+                rows = np.minimum(tile_rows, nr[nat["level"]] - nat["ty"].astype(np.int64) * tile_rows)
+                cols = np.minimum(tile_cols, nc[nat["level"]] - nat["tx"].astype(np.int64) * tile_cols)
+                cost = rows * cols / float(tile_rows * tile_cols)
+                return cost < 1.0, cost
+        return self._tiles(grid, tile_rows, tile_cols, cheap=cheap)
 
     def n_loc(self, m, n):
         return int(sum(r * c for r, c in self.window_grid(m, n)))
