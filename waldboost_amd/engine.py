@@ -316,6 +316,9 @@ def sort_records(d):
     return d[torch.argsort(key)].contiguous()
 
 
+_SHORT_LAST_BATCH = 2            # images per launch up to which the tile lists end with the short workgroups (plan._tiles)
+
+
 class CapturedStep:
     """A hipGraph of one engine's step (PyramidEngine.capture).  The graph holds device ADDRESSES: of the control block
     and of the detection buffer, both of which the engine re-allocates when they must grow.  replay() refuses to run
@@ -366,7 +369,7 @@ class PyramidEngine:
         self.exact_single = exact_single
         p = self.plan
         # (tile lists with the short workgroups last: for one or two images per launch -- plan._tiles)
-        p.short_last = p.short_last and self.batch <= 2
+        p.short_last = p.short_last and (self.batch <= _SHORT_LAST_BATCH or os.environ.get("WB_TILE_ORDER") == "short")
         dev = self.dev
         # flat allocations with 16 spare elements: the channel kernel fetches source rows with
         # 4-byte-aligned dword loads that may touch a few bytes past the last row
