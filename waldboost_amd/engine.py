@@ -316,7 +316,7 @@ def sort_records(d):
     return d[torch.argsort(key)].contiguous()
 
 
-_SHORT_LAST_BATCH = 2            # images per launch up to which the tile lists end with the short workgroups (plan._tiles)
+_SHORT_LAST_BATCH = 4            # images per launch up to which the tile lists end with the short workgroups (plan._tiles)
 
 
 class CapturedStep:

@@ -94,7 +94,8 @@ class PyramidPlan:
         self._table = None
         self._chan_tiles = None
         # tile lists with the workgroups known to be short dispatched last on every XCD (_tiles): the engine keeps it for
-        # batches of one or two images -- with more, a launch is image after image of the same list and only its very end
+        # batches of up to four images (measured: +3 % at 2, +1 % at 4, nothing from 8 on, -1 % at 64) -- a launch of more is
+        # image after image of the same list and only its very end
         # has a tail -- and WB_TILE_ORDER=natural switches it off (A/B runs)
         self.short_last = os.environ.get("WB_TILE_ORDER", "") != "natural"
 
