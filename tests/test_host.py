@@ -362,8 +362,9 @@ def test_tile_lists_dispatch_the_short_workgroups_last_on_every_xcd():
     others, costliest first; a plan with short_last off (large batches, WB_TILE_ORDER=natural) keeps the plain order."""
     for args in [(1080, 1920, 2, 8, 1), (300, 500, 2, 4, 1), (64, 64, 2, 8, 1)]:
         p, q = PyramidPlan(*args), PyramidPlan(*args)
-        q.short_last = False
-        assert p.short_last
+        q.batch_hint = 64                                     # (a large batch keeps the plain order when the tile counts rotate the XCDs)
+        assert p._short_last(3421) and not q._short_last(3421) and q._short_last(19224) and q._short_last(12)
+        q._short_last = lambda n: False
         tc, tc0 = p.chan_tiles(), q.chan_tiles()
         tk, tk0 = p.casc_tiles(12, 12, 32, 64), q.casc_tiles(12, 12, 32, 64)
         assert sorted(map(tuple, tc.tolist())) == sorted(map(tuple, tc0.tolist()))

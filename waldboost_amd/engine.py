@@ -316,9 +316,6 @@ def sort_records(d):
     return d[torch.argsort(key)].contiguous()
 
 
-_SHORT_LAST_BATCH = 4            # images per launch up to which the tile lists end with the short workgroups (plan._tiles)
-
-
 class CapturedStep:
     """A hipGraph of one engine's step (PyramidEngine.capture).  The graph holds device ADDRESSES: of the control block
     and of the detection buffer, both of which the engine re-allocates when they must grow.  replay() refuses to run
@@ -368,8 +365,7 @@ class PyramidEngine:
                                 n_chn=self.spec.n_channels, chn_bytes=self.spec.dtype.itemsize, chan_func=self.spec.func_id)
         self.exact_single = exact_single
         p = self.plan
-        # (tile lists with the short workgroups last: for one or two images per launch -- plan._tiles)
-        p.short_last = p.short_last and (self.batch <= _SHORT_LAST_BATCH or os.environ.get("WB_TILE_ORDER") == "short")
+        p.batch_hint = self.batch     # (the tile lists' dispatch order depends on the images per launch: plan._short_last)
         dev = self.dev
         # flat allocations with 16 spare elements: the channel kernel fetches source rows with
         # 4-byte-aligned dword loads that may touch a few bytes past the last row

@@ -93,11 +93,22 @@ class PyramidPlan:
 
         self._table = None
         self._chan_tiles = None
-        # tile lists with the workgroups known to be short dispatched last on every XCD (_tiles): the engine keeps it for
-        # batches of up to four images (measured: +3 % at 2, +1 % at 4, nothing from 8 on, -1 % at 64) -- a launch of more is
-        # image after image of the same list and only its very end
-        # has a tail -- and WB_TILE_ORDER=natural switches it off (A/B runs)
-        self.short_last = os.environ.get("WB_TILE_ORDER", "") != "natural"
+        # tile lists with the workgroups known to be short dispatched last on every XCD (_tiles, _short_last); the engine
+        # says how many images a launch holds
+        self.batch_hint = 1
+
+    def _short_last(self, n_tiles):
+        """Whether a list of n_tiles tiles is dealt with the short workgroups last on every XCD -- which also hands every XCD
+        an even share of the long ones.  Contiguous eighths of the level-major list give one XCD the largest level's full
+        tiles and another the small levels' cut ones; with several images per launch the dispatch phase of image y is
+        (y * n_tiles) mod 8, so the shares rotate over the XCDs -- unless n_tiles is a multiple of 8 or 4 (4K, shrink 4:
+        19224 channel tiles, the same XCD takes the same share of every image: 252 against 240 us per image at any
+        batch size).  Measured at 1080p (3421 / 1670 tiles, full rotation): +3 % at batch 2, +1 % at 4, nothing at 8 and
+        16, -1 % at 64 (the plain order keeps neighbouring tiles on one XCD's L2).  WB_TILE_ORDER=natural / short: A/B runs."""
+        mode = os.environ.get("WB_TILE_ORDER", "")
+        if mode in ("natural", "short"):
+            return mode == "short"
+        return self.batch_hint <= 4 or n_tiles % 8 in (0, 4)
 
     # ------------------------------------------------------------------ layout
     def chn_offsets(self):
@@ -158,7 +169,7 @@ class PyramidPlan:
 
     # ------------------------------------------------------------------ tiles
     @staticmethod
-    def _tiles(dims, tr, tc, cheap=None):
+    def _tiles(dims, tr, tc, cheap=None, short_last=lambda n: True):
         """dims: per level (rows, cols) to cover with tr x tc tiles; natural order, XCD-permuted.
         cheap: callable(tiles in natural order) -> (bool mask of the tiles known to be SHORT workgroups -- the channel
         kernel's identity levels (a copy instead of a resample), tiles cut by the edge of their level --, their relative
@@ -177,7 +188,7 @@ class PyramidPlan:
         if not parts:
             return np.zeros(0, TILE_DTYPE)
         nat = np.concatenate(parts)
-        if cheap is not None:
+        if cheap is not None and short_last(nat.size):
             mask, cost = cheap(nat)
             a, b = nat[~mask], nat[mask]
             b = b[np.argsort(-cost[mask], kind="stable")]
@@ -214,19 +225,17 @@ class PyramidPlan:
     def chan_tiles(self):
         if self._chan_tiles is None:
             tu, tv = chan_tile(self.chan_func, self.shrink)
-            cheap = None
-            if self.short_last:
-                # the channel kernel's short workgroups: tiles of identity levels (level = its octave's own size: a copy
-                # instead of a resample, 8 against 12.5 ns per tile) and tiles cut by the bottom edge of their level (the
-                # kernel computes only the rows they hold)
-                ident = np.array([lv["h"] == lv["nh"] and lv["w"] == lv["nw"] for lv in self.levels], bool)
-                us = np.array([lv["u"] for lv in self.levels], np.int64)
+            # the channel kernel's short workgroups: tiles of identity levels (level = its octave's own size: a copy
+            # instead of a resample, 8 against 12.5 ns per tile) and tiles cut by the bottom edge of their level (the
+            # kernel computes only the rows they hold)
+            ident = np.array([lv["h"] == lv["nh"] and lv["w"] == lv["nw"] for lv in self.levels], bool)
+            us = np.array([lv["u"] for lv in self.levels], np.int64)
 
-                def cheap(nat):
-                    rows = np.minimum(tu, us[nat["level"]] - nat["ty"].astype(np.int64) * tu)   # output rows the tile holds
-                    cost = np.where(ident[nat["level"]], 0.65, 1.0) * (0.35 + 0.65 * rows / tu)
-                    return ident[nat["level"]] | (rows < tu), cost
-            self._chan_tiles = self._tiles([(lv["u"], lv["v"]) for lv in self.levels], tu, tv, cheap=cheap)
+            def cheap(nat):
+                rows = np.minimum(tu, us[nat["level"]] - nat["ty"].astype(np.int64) * tu)   # output rows the tile holds
+                cost = np.where(ident[nat["level"]], 0.65, 1.0) * (0.35 + 0.65 * rows / tu)
+                return ident[nat["level"]] | (rows < tu), cost
+            self._chan_tiles = self._tiles([(lv["u"], lv["v"]) for lv in self.levels], tu, tv, cheap=cheap, short_last=self._short_last)
         return self._chan_tiles
 
     def window_grid(self, m, n):
@@ -236,17 +245,16 @@ class PyramidPlan:
 
     def casc_tiles(self, m, n, tile_rows, tile_cols):
         grid = self.window_grid(m, n)
-        cheap = None
-        if self.short_last:                                   # the cascade's short workgroups: tiles cut by an edge of their level
-            nr = np.array([g[0] for g in grid], np.int64)
-            nc = np.array([g[1] for g in grid], np.int64)
+        # the cascade's short workgroups: tiles cut by an edge of their level
+        nr = np.array([g[0] for g in grid], np.int64)
+        nc = np.array([g[1] for g in grid], np.int64)
 
-            def cheap(nat):
-                rows = np.minimum(tile_rows, nr[nat["level"]] - nat["ty"].astype(np.int64) * tile_rows)
-                cols = np.minimum(tile_cols, nc[nat["level"]] - nat["tx"].astype(np.int64) * tile_cols)
-                cost = rows * cols / float(tile_rows * tile_cols)
-                return cost < 1.0, cost
-        return self._tiles(grid, tile_rows, tile_cols, cheap=cheap)
+        def cheap(nat):
+            rows = np.minimum(tile_rows, nr[nat["level"]] - nat["ty"].astype(np.int64) * tile_rows)
+            cols = np.minimum(tile_cols, nc[nat["level"]] - nat["tx"].astype(np.int64) * tile_cols)
+            cost = rows * cols / float(tile_rows * tile_cols)
+            return cost < 1.0, cost
+        return self._tiles(grid, tile_rows, tile_cols, cheap=cheap, short_last=self._short_last)
 
     def n_loc(self, m, n):
         return int(sum(r * c for r, c in self.window_grid(m, n)))
