@@ -20,7 +20,8 @@ WB_NO_RANKS=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline > $O/bench_de
 WB_CASC_JIT=0 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-jit > $O/bench_default_generic_cascade.json 2>> $O/bench_default.err || exit 1
 WB_CASC_JIT=0 timeout -k 10 300 python3 bench.py --batch 64 --steps 10 --warmup 2 --pool 2 --streams 2 --no-cpu-baseline --no-jit > $O/bench_batch64_generic_cascade.json 2>> $O/bench_default.err || exit 1
 timeout -k 10 300 python3 bench.py --gpus 2 --backend gloo --no-cpu-baseline --steps 20 --warmup 5 2>> $O/bench_default.err | grep "^{" > $O/bench_2ranks_gloo_selflaunch.json || exit 1   # (gloo prints a connection banner on stdout)
-timeout -k 10 300 python3 tools/bench_cfg5.py > $O/bench_cfg5.txt 2>> $O/bench_default.err || exit 1
+timeout -k 10 300 python3 tools/bench_cfg5.py 4 > $O/bench_cfg5.txt 2>> $O/bench_default.err || exit 1
+timeout -k 10 300 python3 tools/bench_cfg5.py 16 >> $O/bench_cfg5.txt 2>> $O/bench_default.err || exit 1
 timeout -k 10 300 python3 tools/bench_next_rows.py > $O/bench_next_rows.txt 2>> $O/bench_default.err || exit 1
 # (the two-model call once more with a read-back that holds the synthetic image's 4000+ detections per model)
 WB_FETCH_ROWS=8192 timeout -k 10 300 python3 tools/bench_next_rows.py 2>> $O/bench_default.err | grep "waldboost.detect" >> $O/bench_next_rows.txt || exit 1
