@@ -160,6 +160,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=10,
                     help="the timed region of --steps steps is run this many times; `value` is the median region, "
                          "`value_spread` carries min/max")
+    ap.add_argument("--warm-ms", type=float, default=50.0,
+                    help="untimed device work in front of the timed regions, in ms (as whole regions of --steps steps): the "
+                         "GPU's clocks ramp for ~20 ms after the idle seconds of the parity gates")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-through-api", action="store_true", help="skip the host ndarray -> Boxes measurement (Model.detect)")
     ap.add_argument("--channels", choices=sorted(MODELS), default="grad_hist",
@@ -475,10 +478,16 @@ def main():
     # the W untimed steps once more, right in front of the timed regions: the parity gates above are seconds of host work
     # with an idle GPU behind them, and the first timed region used to start on a GPU that had clocked down
     # (value_spread.min 11 % under the median in round 2)
-    if region is not None:
-        run_region()
-    else:
-        run_steps(0, args.warmup)
+    # ... and for --warm-ms of device time: after idle seconds the GPU takes about 20 ms of work to reach its steady clocks
+    # (twenty-step regions of 1.3 ms, timed back to back from a cold start: 0.067, 0.065, 0.064, ... 0.0595 ms per step
+    # from the fifteenth on -- value_spread.ms_per_step_by_region shows whatever trend is left).  A count, not a clock:
+    # every rank replays the same number of regions (they hold collectives).
+    n_warm = max(1, int(round(args.warm_ms / max(args.steps * B * 0.06, 1e-3))))
+    for _ in range(n_warm):
+        if region is not None:
+            run_region()
+        else:
+            run_steps(0, max(args.warmup, args.steps))
     dts = []
     for rep in range(max(1, args.repeats)):
         torch.cuda.synchronize()
@@ -590,6 +599,7 @@ def main():
                                                                 else "hipGraph replay per step"), "only": args.only,
                        "channels_in_hbm": "uint8 threshold ranks of the cascade (WB_DTYPE_RANK8)" if fused else spec.dtype.name,
                        "streams": n_streams, "pool": P,
+                       "warm": f"{n_warm} untimed region(s) of {args.steps} steps right before the timed ones (--warm-ms {args.warm_ms:g})",
                        "cascade_kernel": (f"model-specialised (hiprtc at model load, {t_jit:.1f} s incl. cache lookup)" if jit else "generic"),
                        "collective": ("none" if not coll else
                                       "one all_gather of the K steps' packed detection prefixes at the end of every timed region" if gath_region is not None
@@ -598,7 +608,8 @@ def main():
             "images_per_s": world * args.steps * B / dt,
             "pipeline_roofline_frac": (windows / dt) * (ab["total"] / n_loc) / (HBM_PEAK_GBS * 1e9 * world),
             "value_spread": {"repeats": len(dts), "min": windows / max(dts), "max": windows / min(dts),
-                             "ms_per_step_min": min(dts) / args.steps * 1e3, "ms_per_step_max": max(dts) / args.steps * 1e3},
+                             "ms_per_step_min": min(dts) / args.steps * 1e3, "ms_per_step_max": max(dts) / args.steps * 1e3,
+                             "ms_per_step_by_region": [round(x / args.steps * 1e3, 5) for x in dts]},
             "kernels": kern, "parity": parity, "ranks": per_rank, "through_api": through_api,
             "roofline": roof, "issue_bound": issue_bound(roof, B, args.channels), "cpu_baseline": cpu,
         }
