@@ -38,39 +38,89 @@ MODELS = {"grad_hist": os.path.join(ROOT, "tests", "golden", "models", "cfg2_d2_
           # secondary workload: the reference's integer channels, uint8 x4 per pixel
           "grad_hist_4_u1": os.path.join(ROOT, "tests", "golden", "models", "cfg2_gh4u1_d2_T128.pb")}
 MODEL = MODELS["grad_hist"]
+# --config: "2" = BASELINE configs[1] (the headline: what the metric is quoted on; configs[2] / [3] are --batch 64 /
+# --gpus 8 of it), "5" = BASELINE configs[4] (4K, shrink 4 -- this build's extension of the reference's shrink in (1, 2),
+# channels.py:120 --, 12 levels per octave, 256 stages, ~1e-4 survival)
+WORKLOADS = {
+    "2": dict(H=1080, W=1920, name="BASELINE configs[1]", models=MODELS, batch=1, stages=128, cpu_images_per_core=6),
+    "5": dict(H=2160, W=3840, name="BASELINE configs[4]", batch=4, stages=256, cpu_images_per_core=1,
+              models={"grad_hist": os.path.join(ROOT, "tests", "golden", "models", "cfg5_d2_T256.pb")}),
+}
 H, W = 1080, 1920
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+CFG3_IMAGES, CFG3_BATCH, CFG3_SEED0 = 512, 64, 30000      # BASELINE configs[3]: 512 x 1080p, 64 per GPU and launch
 
 
 # ----------------------------------------------------------------------------- CPU baseline
 def _cpu_worker(job):
-    seed, model_path = job
+    seed, model_path, h, w = job
     import waldboost_amd as wb          # host-side .pb reader only; no GPU is touched here
     from util import oracle_detect
     from waldboost_amd.synth import synth_image
     M = wb.load(model_path)
     t0 = time.perf_counter()
-    res = oracle_detect(M, synth_image(H, W, seed))
+    res = oracle_detect(M, synth_image(h, w, seed))
     return res["n_loc"], time.perf_counter() - t0
 
 
-def cpu_baseline(model_path, images_per_core=6, max_cores=16):
+def cpu_baseline(model_path, images_per_core=6, max_cores=16, h=1080, w=1920):
     import multiprocessing as mp
     cores = max(1, min(max_cores, os.cpu_count() or 1))
     n = cores * images_per_core
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
-        out = pool.map(_cpu_worker, [(i, model_path) for i in range(n)])
+        out = pool.map(_cpu_worker, [(i, model_path, h, w) for i in range(n)])
     wall = time.perf_counter() - t0
     windows = sum(o[0] for o in out)
     return {"value": windows / wall, "unit": "windows/s", "cores": cores, "kind": "port",
-            "sample": f"{n} synthetic 1080p images, Pool({cores}) over images, NumPy oracle, {wall:.1f} s wall",
+            "sample": f"{n} synthetic {w}x{h} images, Pool({cores}) over images, NumPy oracle, {wall:.1f} s wall",
             "single_core_windows_per_s": float(np.mean([o[0] / o[1] for o in out]))}
 
 
+def _oracle_worker(job):
+    seed, model_path, h, w, stages = job
+    import waldboost_amd as wb
+    from util import oracle_detect
+    from waldboost_amd.synth import synth_image
+    M = wb.load(model_path)
+    if stages:
+        M.classifier, M.theta = M.classifier[:stages], M.theta[:stages]
+    ref = oracle_detect(M, synth_image(h, w, seed))
+    return seed, {k: ref[k] for k in ("level", "r", "c", "scores", "alive", "n_loc", "n_weak")}
+
+
+def oracle_refs(seeds, model_path, h, w, stages=0):
+    """The oracle's detections for the images the parity gates will look at, computed side by side in a process pool
+    before anything touches the GPU (a 4K image takes the NumPy oracle half a minute)."""
+    import multiprocessing as mp
+    seeds = sorted(set(seeds))
+    if not seeds:
+        return {}
+    with mp.get_context("fork").Pool(min(len(seeds), max(1, os.cpu_count() or 1))) as pool:
+        return dict(pool.map(_oracle_worker, [(sd, model_path, h, w, stages) for sd in seeds]))
+
+
+def _synth_worker(job):
+    from waldboost_amd.synth import synth_image
+    return synth_image(job[1], job[2], job[0])
+
+
+def synth_shard(lo, hi, h, w, procs):
+    """Images lo..hi-1 of the configs[3] batch (seeds CFG3_SEED0 + index), uint8 [hi - lo, h, w], generated by a small
+    process pool before anything touches the GPU."""
+    import multiprocessing as mp
+    if hi <= lo:
+        return np.zeros((0, h, w), np.uint8)
+    jobs = [(CFG3_SEED0 + i, h, w) for i in range(lo, hi)]
+    if procs <= 1:
+        return np.stack([_synth_worker(j) for j in jobs])
+    with mp.get_context("fork").Pool(procs) as pool:
+        return np.stack(pool.map(_synth_worker, jobs, chunksize=2))
+
+
 # ----------------------------------------------------------------------------- helpers
-PROFILE_DIR = next((d for d in (os.path.join(ROOT, "profiles", r) for r in ("r03", "r02"))
+PROFILE_DIR = next((d for d in (os.path.join(ROOT, "profiles", r) for r in ("r04", "r03", "r02"))
                     if os.path.exists(os.path.join(d, "sq_counters.json"))), os.path.join(ROOT, "profiles", "r02"))
 N_SIMD, CLOCK_GHZ = 256 * 4, 2.4          # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz max clock
 
@@ -89,7 +139,7 @@ def issue_bound(roof, batch, channels):
     at 2.5).  frac = floor / measured.  wave_time = where a wave's lifetime goes, from the same counters: issuing
     instructions, ready but waiting for an issue slot, waiting on memory / LDS / a barrier."""
     path = os.path.join(PROFILE_DIR, "sq_counters.json")
-    if roof is None or channels != "grad_hist" or not os.path.exists(path):
+    if roof is None or channels != "grad_hist" or not os.path.exists(path) or roof.get("config", "2") != "2":
         return None
     with open(path) as f:
         k = json.load(f).get(roof["kernel"])
@@ -109,9 +159,16 @@ def issue_bound(roof, batch, channels):
     if wc:
         wave_time = {"issuing": g("SQ_ACTIVE_INST_ANY") / wc, "waiting_for_issue_slot": g("SQ_WAIT_INST_ANY") / wc,
                      "waiting_on_data_or_barrier": g("SQ_WAIT_ANY") / wc}
-    return {"kernel": roof["kernel"], "bound": "valu_issue", "valu_insts_per_launch": valu, "of_which_fp32_add_mul_fma": fast,
+    # the same figure from TIME instead of the busy counter (SQ_ACTIVE_INST_VALU is nearly SQ_INSTS_VALU in quad-cycles, so
+    # the counter-derived 4.05 is partly an identity of units): the measured launch time x SIMDs x clock / instructions --
+    # SIMD-cycles that ELAPSED per wave64 VALU instruction issued, waits included
+    time_cycles_per_valu = (roof["avg_launch_ms"] * 1e-3 * N_SIMD * CLOCK_GHZ * 1e9 / valu) if valu else None
+    return {"source": f"{os.path.relpath(path, ROOT)} (committed rocprofv3 --pmc SQ passes; instruction counts are NOT measured in this "
+                      "run, only measured_us is)",
+            "kernel": roof["kernel"], "bound": "valu_issue", "valu_insts_per_launch": valu, "of_which_fp32_add_mul_fma": fast,
             "salu_insts_per_launch": salu, "floor_us": floor_us, "measured_us": roof["avg_launch_ms"] * 1e3,
             "frac": floor_us / (roof["avg_launch_ms"] * 1e3), "valu_busy": valu_busy, "cycles_per_valu": cycles_per_valu,
+            "time_cycles_per_valu": time_cycles_per_valu,
             "wave_time": wave_time, "counters": os.path.relpath(path, ROOT),
             "note": "2.5 issue cycles per wave64 fp32 add/mul/fma, 4.3 per other VALU instruction (measured classes); "
                     "1024 SIMDs at 2.4 GHz"}
@@ -152,7 +209,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=1, help="1080p images per step and GPU (configs[1] = 1, configs[2] = 64)")
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="2",
+                    help="2: BASELINE configs[1] (1080p, shrink 2, 8 per octave, 128 stages -- the headline metric's workload); "
+                         "5: BASELINE configs[4] (4K, shrink 4, 12 per octave, 256 stages; 4 images per step by default)")
+    ap.add_argument("--batch", type=int, default=0, help="images per step and GPU (default: 1 for --config 2 = configs[1]; "
+                                                          "configs[2] is --batch 64; 4 for --config 5)")
+    ap.add_argument("--no-config3", action="store_true",
+                    help="skip the configs[3] measurement (512 x 1080p cut over the ranks by shard_range, 64 images per launch, "
+                         "through distributed.detect_sharded with its end-of-batch exchange) that every line carries")
+    ap.add_argument("--config3-images", type=int, default=CFG3_IMAGES, help="diagnostic: size of the configs[3] batch")
     ap.add_argument("--pool", type=int, default=4, help="distinct resident image batches cycled through")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the steps are spread over (<= pool): consecutive steps work on different "
@@ -187,9 +252,23 @@ def main():
                          "the launch path on a machine without GPUs")
     args = ap.parse_args()
 
+    global H, W
+    wl = WORKLOADS[args.config]
+    H, W = wl["H"], wl["W"]
+    if args.channels not in wl["models"]:
+        raise SystemExit(f"--config {args.config} has no {args.channels} model")
+    model_path = wl["models"][args.channels]
+    if not args.batch:
+        args.batch = wl["batch"]
+    want_cpu = not args.no_cpu_baseline and args.only == "all" and not args.dry_launch
     if args.no_jit:
         os.environ["WB_CASC_JIT"] = "0"                       # (also the engine's own after-a-few-scans policy; children inherit it)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the CPU baseline of a self-launched multi-rank run: timed HERE, on the otherwise idle host, before any rank
+        # exists, and handed to rank 0 through the environment (a multi-rank line carries it like a single-rank one)
+        if want_cpu and os.path.exists("/dev/kfd"):
+            os.environ["WB_BENCH_CPU_BASELINE"] = json.dumps(
+                cpu_baseline(model_path, images_per_core=wl["cpu_images_per_core"], h=H, w=W))
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -220,9 +299,36 @@ def main():
         dist.destroy_process_group()
         return
 
+    if not os.path.exists("/dev/kfd"):                       # (no ROCm device node: fail before the minutes of host-side preparation)
+        raise SystemExit("bench.py needs a GPU (no /dev/kfd on this machine); --dry-launch checks the launch path without one")
     cpu = None
-    if world == 1 and not args.no_cpu_baseline and args.only == "all":
-        cpu = cpu_baseline(MODELS[args.channels])            # before the GPU is initialised (fork-safe)
+    if rank == 0 and want_cpu:
+        if os.environ.get("WB_BENCH_CPU_BASELINE"):
+            cpu = json.loads(os.environ["WB_BENCH_CPU_BASELINE"])      # (timed by the launching parent, see above)
+        else:
+            # before the GPU is initialised (fork-safe); with a launcher's ranks around it (torch.distributed.run started
+            # by the caller) the other ranks are generating their configs[3] images meanwhile: said in `sample`
+            cpu = cpu_baseline(model_path, images_per_core=wl["cpu_images_per_core"], h=H, w=W)
+            if world > 1:
+                cpu["sample"] += f"; timed on rank 0 while {world - 1} other rank(s) prepared their inputs on the same host"
+    # BASELINE configs[3]'s batch: THIS rank's contiguous shard of the 512 images, generated now (process pool, before
+    # anything touches the GPU)
+    cfg3_host = None
+    do_cfg3 = args.config == "2" and args.channels == "grad_hist" and args.only == "all" and not args.no_config3 and not args.stages
+    if do_cfg3:
+        from waldboost_amd.distributed import shard_range
+        lo3, hi3 = shard_range(args.config3_images, rank, world)
+        t_gen = time.perf_counter()
+        cfg3_host = synth_shard(lo3, hi3, H, W, max(1, min(16, (os.cpu_count() or 1) // max(world, 1))))
+        t_gen = time.perf_counter() - t_gen
+
+    # the oracle's answers for the images the parity gates check (first and last image of the first and the last engine's
+    # batch), computed now, in parallel
+    gate_refs = {}
+    if args.only == "all" and not args.stages:
+        Pn, Bn = max(1, args.pool), args.batch
+        gate_refs = oracle_refs([(rank * Pn + j) * Bn + b for j in {0, min(Pn, args.steps) - 1} for b in {0, Bn - 1}],
+                                model_path, H, W)
 
     import torch
     import torch.distributed as dist
@@ -249,8 +355,9 @@ def main():
     from waldboost_amd.synth import synth_image
     from waldboost_amd.distributed import RoundGatherer
 
-    M = wb.load(MODELS[args.channels])
+    M = wb.load(model_path)
     spec = wb.channels.channel_spec(M.channel_opts["channels"])
+    shrink, n_per_oct, smooth = (int(M.channel_opts[k]) for k in ("shrink", "n_per_oct", "smooth"))
     if args.stages:
         M.classifier, M.theta = M.classifier[:args.stages], M.theta[:args.stages]
     dm = M.device_cascade()
@@ -267,7 +374,7 @@ def main():
     B, P = args.batch, max(1, args.pool)
     engines = []
     for i in range(P):
-        e = PyramidEngine(H, W, np.uint8, 2, 8, 1, batch=B, det_capacity=16384 * B, channels=spec)
+        e = PyramidEngine(H, W, np.uint8, shrink, n_per_oct, smooth, batch=B, det_capacity=16384 * B, channels=spec)
         seeds = [(rank * P + i) * B + b for b in range(B)]
         e.load_images(np.stack([synth_image(H, W, s) for s in seeds]))
         engines.append(e)
@@ -317,7 +424,10 @@ def main():
         j0 = engines.index(e)
         for b in sorted({0, B - 1}):
             db = d[d["image"] == b]
-            ref = oracle_detect(M, synth_image(H, W, (rank * P + j0) * B + b))
+            seed = (rank * P + j0) * B + b
+            if seed not in gate_refs:
+                gate_refs[seed] = oracle_detect(M, synth_image(H, W, seed))
+            ref = gate_refs[seed]
             ok = (np.array_equal(db["level"], ref["level"]) and np.array_equal(db["r"], ref["r"]) and
                   np.array_equal(db["c"], ref["c"]) and np.array_equal(db["score"].view(np.uint32), ref["scores"].view(np.uint32)) and
                   np.array_equal(alive[b], ref["alive"]))
@@ -482,7 +592,7 @@ def main():
     # (twenty-step regions of 1.3 ms, timed back to back from a cold start: 0.067, 0.065, 0.064, ... 0.0595 ms per step
     # from the fifteenth on -- value_spread.ms_per_step_by_region shows whatever trend is left).  A count, not a clock:
     # every rank replays the same number of regions (they hold collectives).
-    n_warm = max(1, int(round(args.warm_ms / max(args.steps * B * 0.06, 1e-3))))
+    n_warm = max(1, int(round(args.warm_ms / max(args.steps * B * (0.06 if args.config == "2" else 0.35), 1e-3))))
     for _ in range(n_warm):
         if region is not None:
             run_region()
@@ -534,27 +644,31 @@ def main():
         name = "channels_kernel" if kern["channels_ms"] >= kern["cascade_tile_ms"] else "cascade_kernel"
         ms = kern["channels_ms"] if name == "channels_kernel" else kern["cascade_tile_ms"]
         abytes = ab[name] * B
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (batch-1 launches only)
-        traffic = None
-        tpath = os.path.join(PROFILE_DIR, "traffic_pmc.json")
-        if os.path.exists(tpath) and B == 1 and args.channels == "grad_hist":
+        # HBM bytes per launch: NOT measured in this run -- read from the committed rocprofv3 PMC passes (batch-1 launches of
+        # the configs[1] workload only); `traffic_source` says so in the line
+        traffic = tsrc = None
+        tpath = os.path.join(PROFILE_DIR, "traffic_pmc.json" if args.config == "2" else f"traffic_pmc_cfg{args.config}.json")
+        if os.path.exists(tpath) and B == wl["batch"] and args.channels == "grad_hist":
             with open(tpath) as f:
                 tj = json.load(f)
             key = "channels_kernel" if name == "channels_kernel" else "cascade_tile_kernel"
-            traffic = tj.get(key, {}).get("traffic_bytes_per_launch_b1")
-        roof = {"bound": "hbm", "kernel": "channels_kernel" if name == "channels_kernel" else "cascade_tile_kernel", "achieved": abytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            traffic = tj.get(key, {}).get("traffic_bytes_per_launch_b1" if args.config == "2" else "traffic_bytes_per_launch")
+            if traffic is not None:
+                tsrc = f"{os.path.relpath(tpath, ROOT)} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured in this run)"
+        roof = {"config": args.config, "bound": "hbm", "kernel": "channels_kernel" if name == "channels_kernel" else "cascade_tile_kernel", "achieved": abytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                 # what the hardware sees: the rank path writes one byte per channel value instead of SURVEY 8(d)'s float32
                 # and most source re-reads hit the caches, so the bytes MOVED are well below the algorithmic figure --
                 # frac is the contract's number, frac_moved the HBM utilisation (these kernels are VALU-issue-bound:
                 # see issue_bound.valu_busy)
                 "moved_bytes": traffic, "frac_moved": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": ms}
+                "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": ms,
+                "avg_launch_source": "HIP events around back-to-back launches on the launch stream, this run"}
 
     # ---- the same workload through the reference's Python surface: host ndarray in, Boxes out (Model.detect,
     #      reference model.py:149-179) -- PCIe copies, kernels, ordering, boxes, synchronisation; never `value`
     through_api = None
-    if rank == 0 and args.only == "all" and not args.no_through_api and not args.stages:
+    if rank == 0 and args.only == "all" and not args.no_through_api and not args.stages and args.config == "2":
         imgs = [synth_image(H, W, 7000 + i) for i in range(8)]
         for im in imgs[:3]:
             M.detect(im)
@@ -581,25 +695,100 @@ def main():
         through_api["stream"] = dict(stream_rate(1, 200), call="Model.detect_stream(iterable of host uint8 ndarrays) -> Boxes per image, in order")
         through_api["stream_batch16"] = dict(stream_rate(16, 480), call="Model.detect_stream(..., batch=16)")
 
+    # ---- BASELINE configs[3]: 512 x 1080p cut over the ranks by shard_range, every rank's shard resident on its GPU and
+    #      scanned 64 images per launch through the PRODUCT's multi-GPU entry, distributed.detect_sharded -- its chunked
+    #      two-stream scan, agree_capacity (all-reduce MAX), the ordering of the records on the device, the gather of the
+    #      records to rank 0 and the all-reduce (SUM) of alive[level, stage] all inside the timed call.  What the
+    #      reference's detection script does with a process pool over files (scripts/waldboost-detect.py:64-67).  At N = 1
+    #      this is the curve's first point (eight launches of 64, one rank in the RCCL group); at N = 8 BASELINE configs[3].
+    config3 = None
+    if do_cfg3:
+        from waldboost_amd import distributed as wbd
+        own_group = not dist.is_initialized()
+        if own_group:                                        # (a single rank with no launcher: a one-rank RCCL group)
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(so.getsockname()[1]))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev), rank=0, world_size=1)
+            else:
+                dist.init_process_group(args.backend, rank=0, world_size=1)
+        cdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        n3 = args.config3_images
+        shard = torch.from_numpy(cfg3_host).to(engines[0].dev)                  # this rank's images, resident
+        del cfg3_host
+        walls, scans, dets = [], [], None
+        for rep in range(4):                                  # the first call is untimed: buffers, graphs, capacity growth
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            det3, _, total3 = wbd.detect_sharded(M, shard, batch=CFG3_BATCH, per_image_alive=False)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            dt3 = torch.tensor([time.perf_counter() - t0, wbd.LAST_TIMING.get("scan_s", 0.0)], dtype=torch.float64, device=cdev)
+            allt = torch.zeros((world, 2), dtype=torch.float64, device=cdev)
+            dist.all_gather_into_tensor(allt, dt3.view(1, 2))
+            if rep:
+                walls.append(float(allt[:, 0].max()))
+                scans.append([float(x) for x in allt[:, 1].tolist()])
+        if rank == 0:
+            wall3 = float(np.median(walls))
+            # rank 0's merged result against the single-image entry point, Model.detect_raw, for the first, the middle and
+            # the last image of the global batch (regenerated here from their seeds)
+            checked = []
+            for g in sorted({0, n3 // 2, n3 - 1}):
+                ref = M.detect_raw(synth_image(H, W, CFG3_SEED0 + g))
+                mine = det3[det3["image"] == g]
+                same = (mine.size == ref["scores"].size and np.array_equal(mine["level"], ref["level"]) and
+                        np.array_equal(mine["r"], ref["r"].astype(np.uint16)) and np.array_equal(mine["c"], ref["c"].astype(np.uint16)) and
+                        np.array_equal(mine["score"].view(np.uint32), ref["scores"].view(np.uint32)))
+                if not same:
+                    raise SystemExit(f"bench: configs[3]: image {g} of the gathered detections differs from Model.detect_raw")
+                checked.append({"image": g, "detections": int(mine.size)})
+            config3 = {
+                "workload": f"BASELINE configs[3]: {n3} x 1920x1080 uint8 (seeds {CFG3_SEED0}+i) cut over {world} rank(s) by shard_range, each "
+                            f"shard resident in HBM and scanned {CFG3_BATCH} images per launch by waldboost_amd.distributed.detect_sharded; "
+                            "timed: the whole call between two barriers -- chunked scan on two streams, agree_capacity, ordering on "
+                            "the device, gather of the records to rank 0 (+ their read-back to host memory), all-reduce of alive[level, stage]",
+                "images": n3, "n_gpus": world, "images_per_rank": [wbd.shard_range(n3, r, world)[1] - wbd.shard_range(n3, r, world)[0] for r in range(world)],
+                "images_per_launch": CFG3_BATCH, "backend": dist.get_backend(),
+                "wall_ms": wall3 * 1e3, "wall_ms_all": [round(w * 1e3, 3) for w in walls], "calls_timed": len(walls), "calls_untimed": 1,
+                "windows_per_s": n3 * n_loc / wall3, "images_per_s": n3 / wall3, "scaling": "strong (the batch is fixed, the ranks share it)",
+                "per_rank_scan_ms": [round(x * 1e3, 3) for x in scans[int(np.argsort(walls)[len(walls) // 2])]],
+                "detections": int(det3.size), "n_weak": int(total3.sum()), "eval_cost": float(total3.sum()) / (n3 * n_loc),
+                "check": {"against": "Model.detect_raw per image (level, r, c, score bits)", "images": checked, "bit_exact": True},
+                "host_prep_s": round(t_gen, 2),
+            }
+        del shard
+        if own_group:
+            dist.destroy_process_group()
+
     if rank == 0:
         windows = world * args.steps * B * n_loc
         ab = plan.algorithmic_bytes(1)
+        n_stage = len(M)
         out = {
-            "metric": f"candidate windows/s, 1080p {args.channels} pyramid, 128-stage depth-2 cascade",
+            "metric": f"candidate windows/s, {'1080p' if args.config == '2' else '4K'} {args.channels} pyramid, {n_stage}-stage depth-2 cascade",
             "value": windows / dt, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8 image, f64/f32 channel arithmetic, f32 scores" if args.channels == "grad_hist"
                      else "u8 image, integer channel arithmetic (u8 channels), f32 scores",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: 1920x1080 uint8, shrink=2 n_per_oct=8 smooth=1 {args.channels}, "
-                                   f"window (12,12,4), 128-stage depth-2 cascade, {B} image(s)/step/GPU",
+            "config": {"workload": f"{wl['name']}: {W}x{H} uint8, shrink={shrink} n_per_oct={n_per_oct} smooth={smooth} {args.channels}, "
+                                   f"window (12,12,4), {n_stage}-stage depth-2 cascade, {B} image(s)/step/GPU"
+                                   + (" (shrink 4 is this build's extension of the reference's shrink in (1, 2): oracle-defined)" if shrink == 4 else ""),
                        "batch_per_gpu": B, "levels": plan.n_levels, "windows_per_image": n_loc,
                        "launch": "eager" if args.no_graph else ("one hipGraph replay per stream and timed region of K steps" if region is not None
                                                                 else "hipGraph replay per step"), "only": args.only,
                        "channels_in_hbm": "uint8 threshold ranks of the cascade (WB_DTYPE_RANK8)" if fused else spec.dtype.name,
                        "streams": n_streams, "pool": P,
                        "warm": f"{n_warm} untimed region(s) of {args.steps} steps right before the timed ones (--warm-ms {args.warm_ms:g})",
+                       "warm_steps_untimed": args.warmup + n_warm * (args.steps if region is not None else max(args.warmup, args.steps)),
                        "cascade_kernel": (f"model-specialised (hiprtc at model load, {t_jit:.1f} s incl. cache lookup)" if jit else "generic"),
                        "collective": ("none" if not coll else
                                       "one all_gather of the K steps' packed detection prefixes at the end of every timed region" if gath_region is not None
@@ -612,6 +801,7 @@ def main():
                              "ms_per_step_by_region": [round(x / args.steps * 1e3, 5) for x in dts]},
             "kernels": kern, "parity": parity, "ranks": per_rank, "through_api": through_api,
             "roofline": roof, "issue_bound": issue_bound(roof, B, args.channels), "cpu_baseline": cpu,
+            "config3": config3,
         }
         emit(out)
     if coll:

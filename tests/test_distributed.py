@@ -248,6 +248,17 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     assert out["ranks"] == [0, 1] and out["local_ranks"] == [0, 1] and out["steps"] == 2
 
 
+def test_bench_dry_launch_reaches_rank_0_with_eight_ranks():
+    """BASELINE configs[3]'s launch shape, `--gpus 8`: eight ranks rendezvous (gloo, CPU) and rank 0 prints the one line."""
+    import json
+    r = _run_bench("--gpus", "8", "--dry-launch", "--steps", "20", "--warmup", "5")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout
+    out = json.loads(r.stdout)
+    assert out["dry_launch"] and out["n_gpus"] == 8 and out["world_size_reported"] == 8
+    assert out["ranks"] == list(range(8)) and out["local_ranks"] == list(range(8))
+
+
 def test_bench_propagates_a_failing_rank():
     """Without a GPU the real run cannot start: every rank exits non-zero with a clear message and the parent
     returns that failure instead of hanging or printing a line."""

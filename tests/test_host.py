@@ -212,6 +212,44 @@ def test_device_cascade_cache_follows_the_content_of_the_stage_list(monkeypatch)
     assert M2.device_cascade() is not e0 and M.device_cascade() is not d5
 
 
+@pytest.mark.parametrize("how", ["deepcopy", "copy", "pickle"])
+def test_copied_and_unpickled_models_keep_following_in_place_edits(monkeypatch, how):
+    """copy.deepcopy / pickle copy every NumPy view on its own: a restored DTree must get a block of its own that its five
+    arrays are views of again, or an in-place edit of the copy would never reach content() and the copy would go on
+    scanning with the stale GPU cascade (reference Model / DTree are plain objects: model.py:62-67, training.py:24-31)."""
+    import copy
+    import pickle
+    from waldboost_amd import engine
+
+    class FakeCascade:
+        def __init__(self, shape, classifier, theta):
+            self.snapshot = [w.threshold.copy() for w in classifier]
+
+    monkeypatch.setattr(engine, "DeviceCascade", FakeCascade)
+    M = wb.load(os.path.join(GOLDEN, "mixed_d2_T24.pb"))
+    M.classifier[2].note = "kept"                             # (whatever else a caller hung on a tree travels too)
+    M.device_cascade()
+    N = {"deepcopy": copy.deepcopy, "copy": lambda m: copy.copy(m),
+         "pickle": lambda m: pickle.loads(pickle.dumps(m))}[how](M)
+    if how == "copy":
+        N.classifier = [copy.copy(w) for w in N.classifier]   # (a shallow model copy shares its trees: copy those)
+    for w, w0 in zip(N.classifier, M.classifier):
+        assert w is not w0 and w._blob is not None
+        for a in ("threshold", "prediction", "feature", "left", "right"):
+            assert np.shares_memory(getattr(w, a), w._blob) and not np.shares_memory(getattr(w, a), getattr(w0, a))
+            assert np.array_equal(getattr(w, a), getattr(w0, a)) and getattr(w, a).dtype == getattr(w0, a).dtype
+        assert np.array_equal(w.node, w0.node) and np.array_equal(w.node_idx, w0.node_idx)
+    assert N.classifier[2].note == "kept"
+    d0 = N.device_cascade()
+    assert N.device_cascade() is d0
+    before = bytes(N.classifier[5].content())
+    N.classifier[5].threshold[0] = 9                          # in place, on the copy
+    assert bytes(N.classifier[5].content()) != before
+    d1 = N.device_cascade()
+    assert d1 is not d0 and d1.snapshot[5][0] == 9
+    assert M.classifier[5].threshold[0] != 9                  # the original is untouched
+
+
 def test_boxes_container():
     b = wb.Boxes(np.arange(8, dtype=np.float32).reshape(2, 4), scores=np.array([1.0, 2.0], np.float32))
     assert len(b) == 2 and b.has_field("scores") and not b.has_field("label")

@@ -158,12 +158,32 @@ def agree_capacity(scan, group=None):
         rounds += 1
 
 
-def gather_records(recs, n_images, group=None, dst=0, first_image=None):
-    """Gather every rank's valid detection records (int32 [n, 4] = WbDet rows with LOCAL image indices) to rank
-    `dst`: an all-gather of (n, n_images) per rank, then one gather of the prefixes padded to the longest.
-    Image indices become global: rank r's image i -> first_image[r] + i, by default the ranks' contiguous shards
-    in rank order.  Returns on `dst` the merged WbDet array in reference order (image, level, r, c); on the
-    other ranks None."""
+_PINNED = {}
+
+
+def _to_host(t):
+    """A device int32 [n, 4] tensor as a host ndarray through a cached page-locked buffer (25 MB of records take ~1 ms this
+    way, several from pageable memory)."""
+    import torch
+    if t.device.type != "cuda":
+        return t.numpy()
+    n = t.shape[0]
+    buf = _PINNED.get("recs")
+    if buf is None or buf.shape[0] < n:
+        buf = _PINNED["recs"] = torch.empty((max(n, 1 << 16), 4), dtype=torch.int32).pin_memory()
+    buf[:n].copy_(t, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return buf[:n].numpy()
+
+
+def gather_records(recs, n_images, group=None, dst=0, first_image=None, presorted=False):
+    """Gather every rank's valid detection records (int32 [n, 4] = WbDet rows with LOCAL image indices; a device tensor
+    stays on the device with RCCL) to rank `dst`: an all-gather of (n, n_images) per rank, then one gather of the
+    prefixes padded to the longest.  Image indices become global: rank r's image i -> first_image[r] + i, by default
+    the ranks' contiguous shards in rank order.  Returns on `dst` the merged WbDet array in reference order
+    (image, level, r, c); on the other ranks None.
+    presorted: every rank's records are already in that order (detect_sharded orders them on the device) -- with
+    contiguous shards the merge is then the concatenation in rank order, no host sort."""
     import torch
     import torch.distributed as dist
     from ._native import DET_DTYPE
@@ -174,21 +194,32 @@ def gather_records(recs, n_images, group=None, dst=0, first_image=None):
     dist.all_gather_into_tensor(meta, torch.tensor([[recs.shape[0], int(n_images)]], dtype=torch.int64, device=dev), group=group)
     meta = meta.cpu().numpy()
     n_max = int(meta[:, 0].max())
-    send = torch.zeros((max(n_max, 1), 4), dtype=torch.int32, device=dev)
-    send[: recs.shape[0]] = recs.to(dev)
-    dst_global = dist.get_global_rank(group, dst) if group is not None else dst
-    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, bufs, dst=dst_global, group=group)
+    if world == 1:
+        bufs = [recs]                                          # (nothing to move)
+    else:
+        send = torch.zeros((max(n_max, 1), 4), dtype=torch.int32, device=dev)
+        send[: recs.shape[0]] = recs.to(dev)
+        dst_global = dist.get_global_rank(group, dst) if group is not None else dst
+        bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+        dist.gather(send, bufs, dst=dst_global, group=group)
     if rank != dst:
         return None
+    contiguous = first_image is None
     if first_image is None:
         first_image = np.concatenate([[0], np.cumsum(meta[:-1, 1])])
-    parts = []
+    counts = [int(meta[r, 0]) for r in range(world)]
+    if all(bf.device.type == "cuda" for bf in bufs) and sum(counts):
+        allr = torch.cat([bufs[r][: counts[r]] for r in range(world)]) if world > 1 else bufs[0][: counts[0]]
+        host = _to_host(allr).copy()                           # ONE read-back of all ranks' records
+    else:
+        host = np.concatenate([bufs[r][: counts[r]].cpu().numpy() for r in range(world)]) if world else np.zeros((0, 4), np.int32)
+    out = np.ascontiguousarray(host).view(DET_DTYPE).reshape(-1)
+    at = 0
     for r in range(world):
-        d = bufs[r][: int(meta[r, 0])].cpu().numpy().copy().view(DET_DTYPE).reshape(-1)
-        d["image"] += int(first_image[r])
-        parts.append(d)
-    out = np.concatenate(parts)
+        out["image"][at: at + counts[r]] += int(first_image[r])
+        at += counts[r]
+    if presorted and contiguous:
+        return out
     return out[np.lexsort((out["c"], out["r"], out["level"], out["image"]))]
 
 
@@ -201,67 +232,178 @@ def reduce_alive(alive_levels, group=None):
     return t.cpu().numpy()
 
 
-class _EngineScan:
-    """agree_capacity's view of a PyramidEngine + cascade."""
+_PAIR_ENGINES = {}
+LAST_TIMING = {}            # detect_sharded's last call on this rank: scan_s (bench.py reports the per-rank share)
 
-    def __init__(self, eng, dm):
-        self.eng, self.dm = eng, dm
-        self.stt = eng.run(dm)
+
+def _chunk_engine(H, W, dtype, shrink, n_per_oct, smooth, batch, spec, slot):
+    """The engine a chunk of `batch` images is scanned on: two per configuration, so that consecutive chunks alternate
+    between two streams (slot 0 is the package-wide cached engine of that configuration, slot 1 a second one)."""
+    import torch
+    from . import engine as _engine
+    if slot == 0:
+        return _engine.get_engine(H, W, dtype, shrink, n_per_oct, smooth, batch, channels=spec)
+    key = (int(H), int(W), np.dtype(dtype).str, int(shrink), int(n_per_oct), int(smooth), int(batch), spec.key,
+           torch.cuda.current_device())
+    e = _PAIR_ENGINES.get(key)
+    if e is None:
+        if len(_PAIR_ENGINES) >= 2:
+            _PAIR_ENGINES.pop(next(iter(_PAIR_ENGINES)))
+        e = _PAIR_ENGINES[key] = _engine.PyramidEngine(H, W, dtype, shrink, n_per_oct, smooth, batch, channels=spec)
+    return e
+
+
+class _ShardScan:
+    """A rank's scan of its shard, in chunks of `batch` images that alternate between two engines on two streams (chunk
+    k + 1's image copy and first kernels overlap chunk k's tail); every chunk's valid records are packed on the device
+    (wb_det_pack_launch) into a slot of their own.  Also agree_capacity's view of the rank: ``cap``, ``need()``, ``grow()``."""
+
+    def __init__(self, model, images, batch, per_image_alive=True):
+        import torch
+        from . import engine as _engine
+        from . import channels as _channels
+        self.images = images
+        self.b = b = int(images.shape[0])
+        self.H, self.W = int(images.shape[1]), int(images.shape[2])
+        self.opts = _channels.read_opts(model.channel_opts)
+        self.dtype = _engine.array_dtype(images)          # (NotImplementedError before any collective: the same on every rank)
+        self.dm = model.device_cascade()
+        self.T = len(model)
+        self.per_image_alive = per_image_alive
+        batch = max(1, int(batch))
+        self.bounds = [(lo, min(lo + batch, b)) for lo in range(0, b, batch)]
+        shrink, n_per_oct, smooth, spec = self.opts
+        mk = lambda size, slot: _chunk_engine(self.H, self.W, self.dtype, shrink, n_per_oct, smooth, size, spec, slot)
+        # (an empty shard keeps a one-image engine: its capacity still takes part in the agreement)
+        self.engines = [mk(hi - lo, k % 2) for k, (lo, hi) in enumerate(self.bounds)] or [mk(1, 0)]
+        self.plan = self.engines[0].plan
+        self.dev = self.engines[0].dev
+        self.streams = [torch.cuda.Stream(), torch.cuda.Stream()] if len(self.bounds) > 1 else [torch.cuda.current_stream()]
+        self.slots = None
+        self.hdr = np.zeros((0, 4), np.int64)
+        cap = max(e.detb.cap for e in set(self.engines))
+        self._set_cap(cap)
+
+    def _unique_engines(self):
+        seen, out = set(), []
+        for e in self.engines:
+            if id(e) not in seen:
+                seen.add(id(e))
+                out.append(e)
+        return out
+
+    def _set_cap(self, cap):
+        from . import _native as nat
+        for e in self._unique_engines():
+            if e.detb.cap != cap:
+                e.det_capacity = int(cap) * nat.WB_DET_SHARDS
+                e._alloc_det()
+        self.slots = None
 
     @property
     def cap(self):
-        return self.eng.detb.cap
+        return self.engines[0].detb.cap
+
+    def run(self):
+        """Scan every chunk; afterwards self.hdr[k] = (valid records, fullest shard, records present, shard capacity) of
+        chunk k on the host -- ONE synchronisation."""
+        import torch
+        if self.plan.n_levels == 0 or not self.bounds:
+            return
+        L, T = self.plan.n_levels, self.T
+        main = torch.cuda.current_stream()
+        if self.slots is None:
+            self.slots = [torch.empty((1 + e.detb.NS * e.detb.cap, 4), dtype=torch.int32, device=self.dev) for e in self.engines]
+            self.hdr_d = torch.zeros((len(self.bounds), 4), dtype=torch.int32, device=self.dev)
+            self.alive_sum = torch.zeros((len(self.streams), L, max(T, 1)), dtype=torch.int64, device=self.dev)
+            self.alive_d = (torch.zeros((self.b, L, max(T, 1)), dtype=torch.int32, device=self.dev)
+                            if self.per_image_alive else None)
+        self.alive_sum.zero_()
+        for st in self.streams:
+            if st is not main:
+                st.wait_stream(main)
+        for k, ((lo, hi), eng) in enumerate(zip(self.bounds, self.engines)):
+            st = self.streams[k % len(self.streams)]
+            with torch.cuda.stream(st):
+                eng.load_images(self.images[lo:hi])
+                stt = eng.batch_enqueue(self.dm)
+                eng.pack(out=self.slots[k])
+                self.hdr_d[k].copy_(self.slots[k][0])
+                if T:
+                    al = stt["alive"][:, :, :T]
+                    self.alive_sum[k % len(self.streams), :, :T] += al.sum(dim=0, dtype=torch.int64)
+                    if self.alive_d is not None:
+                        self.alive_d[lo:hi, :, :T] = al
+        for st in self.streams:
+            if st is not main:
+                main.wait_stream(st)
+        self.hdr = self.hdr_d.cpu().numpy().astype(np.int64)
 
     def need(self):
-        return self.eng.detb.max_count()
+        return int(self.hdr[:, 1].max(initial=0))
 
     def grow(self, cap):
-        from . import _native as nat
-        self.eng.det_capacity = int(cap) * nat.WB_DET_SHARDS
-        self.eng._alloc_det()
-        self.stt = self.eng.run_cascade(self.dm, ranks=self.stt.get("ranks", False))
+        self._set_cap(cap)
+        self.run()
+
+    def records(self):
+        """This rank's valid records, int32 [n, 4] on the device, image indices local to the shard, in the reference's
+        order (image, level, r, c)."""
+        import torch
+        from .engine import sort_records
+        parts = []
+        for k, (lo, hi) in enumerate(self.bounds):
+            n = int(self.hdr[k, 0])
+            if n:
+                part = self.slots[k][1:1 + n]
+                if lo:
+                    part = part.clone()
+                    part[:, 0] += lo
+                parts.append(part)
+        if not parts:
+            return torch.zeros((0, 4), dtype=torch.int32, device=self.dev)
+        return sort_records(parts[0] if len(parts) == 1 else torch.cat(parts))
 
 
-def detect_sharded(model, images, group=None, dst=0):
+def detect_sharded(model, images, group=None, dst=0, batch=64, per_image_alive=True):
     """Detect on a batch that is split over the ranks of `group` (one process per GPU).  `images` is THIS rank's
     shard [b, H, W] (host array or device tensor; b may differ between ranks, the shards are consecutive in rank
-    order -- `shard_range` cuts a global batch that way).  Every rank scans its shard with no data-path
-    collective; then the exchange described in the module docstring.  Returns
+    order -- `shard_range` cuts a global batch that way).  Every rank scans its shard with no data-path collective, in
+    chunks of `batch` images alternating between two engines on two streams (BASELINE configs[3]: 512 images over 8
+    GPUs = one chunk of 64 per rank; a single GPU takes the same 512 as eight chunks); then the exchange described in
+    the module docstring.  Returns
 
         det    on rank `dst`: all detections as a WbDet array with GLOBAL image indices in reference order
                (image, level, r, c); None on the other ranks
-        alive  [b, levels, stages] of the local shard
+        alive  [b, levels, stages] of the local shard (None with per_image_alive=False: one read-back less)
         total  [levels, stages] summed over all ranks (every rank)
 
     and adds the GLOBAL n_loc / n_weak to the model's counters on every rank (reference model.py:248,252 are
-    plain sums over the images scanned)."""
-    from . import engine as _engine
-    from . import channels as _channels
-    b = int(images.shape[0])
-    shrink, n_per_oct, smooth, spec = _channels.read_opts(model.channel_opts)
-    H, W = int(images.shape[1]), int(images.shape[2])
-    dtype = _engine.array_dtype(images)               # (NotImplementedError before any collective: the same on every rank)
-    dm = model.device_cascade()
-    T = len(model)
-    eng = _engine.get_engine(H, W, dtype, shrink, n_per_oct, smooth, max(b, 1), channels=spec)
-    if eng.plan.n_levels == 0:
+    plain sums over the images scanned; the loop this replaces is scripts/waldboost-detect.py:64-67)."""
+    import torch.distributed as dist
+    from ._native import DET_DTYPE
+    scan = _ShardScan(model, images, batch, per_image_alive)
+    b, T, plan = scan.b, scan.T, scan.plan
+    if plan.n_levels == 0:
         # images smaller than the window: no level, no window, nothing to exchange -- the plan depends on (H, W,
         # channel_opts) only, so every rank returns here together (reference model.py:171-177 yields nothing either)
-        from ._native import DET_DTYPE
-        import torch.distributed as dist
         rank = dist.get_rank(group)
-        return (np.zeros(0, DET_DTYPE) if rank == dst else None), np.zeros((b, 0, T), np.int64), np.zeros((0, T), np.int64)
-    if b:
-        eng.load_images(images)
-    scan = _EngineScan(eng, dm)                       # (a rank with an empty shard scans one blank image and drops it)
+        return ((np.zeros(0, DET_DTYPE) if rank == dst else None),
+                (np.zeros((b, 0, T), np.int64) if per_image_alive else None), np.zeros((0, T), np.int64))
+    import time
+    t0 = time.perf_counter()
+    scan.run()
+    LAST_TIMING.clear()
+    LAST_TIMING["scan_s"] = time.perf_counter() - t0      # this rank's own scan, up to its one synchronisation
     agree_capacity(scan, group)
-    L = eng.plan.n_levels
-    alive = scan.stt["alive"][:b, :, :T].cpu().numpy().astype(np.int64).reshape(b, L, T)
-    counts = eng.shard_counts(dm)
-    recs = eng.detb.valid_records(counts).cpu() if b else np.zeros((0, 4), np.int32)
-    det = gather_records(recs, b, group, dst)
-    tot = reduce_alive(np.concatenate([alive.sum(axis=0).reshape(-1), [b]]), group)
+    L = plan.n_levels
+    det = gather_records(scan.records(), b, group, dst, presorted=True)
+    alive = None
+    if per_image_alive:
+        alive = (scan.alive_d[:, :, :T].cpu().numpy().astype(np.int64) if b else np.zeros((0, L, T), np.int64)).reshape(b, L, T)
+    mine = scan.alive_sum.sum(dim=0)[:, :T].cpu().numpy().reshape(-1) if (b and T) else np.zeros(L * T, np.int64)
+    tot = reduce_alive(np.concatenate([mine, [b]]), group)
     total, n_images = tot[:-1].reshape(L, T), int(tot[-1])
-    model.n_loc += n_images * eng.plan.n_loc(dm.m, dm.n)
+    model.n_loc += n_images * plan.n_loc(scan.dm.m, scan.dm.n)
     model.n_weak += int(total.sum())
     return det, alive, total

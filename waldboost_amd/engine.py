@@ -151,7 +151,11 @@ class DeviceCascade:
         self._owned = True
         self._scans = {}                 # byte-tile scans so far, per channel dtype code
         self._jit_failed = set()
-        self.rank_key = self             # whose rank tables this cascade scans: its own (a RankGroup's for a member view)
+        # whose rank tables this cascade scans: its own (a RankGroup's for a member view).  An opaque token, compared by
+        # identity -- never the cascade or the group itself: a self-reference (or view -> group -> views) is a cycle, and
+        # a cycle's __del__ (wb_model_destroy / wb_rankgroup_destroy: hipFree) would run whenever the cyclic collector
+        # happens to, e.g. inside somebody's stream capture or between a lane's enqueue and collect
+        self.rank_key = object()
         self._read_info()
 
     def _read_info(self):
@@ -172,7 +176,8 @@ class DeviceCascade:
         self.handle = handle
         self._owned = False
         self._scans, self._jit_failed = {}, set()
-        self.rank_key = group
+        self.rank_key = group.token      # (a token, not the group: see __init__)
+        self.group = group               # keeps the handle's owner alive; the group does NOT refer back to its views
         self._read_info()
         return self
 
@@ -226,8 +231,10 @@ class DeviceCascade:
 
 class RankGroup:
     """Several cascades over ONE pyramid of threshold ranks (wb_rankgroup_create): the rank table of every channel is
-    built from the union of the members' thresholds; ``views[i]`` is member i as a DeviceCascade whose rank tables are the
-    group's.  Raises NotImplementedError when the union does not fit (more than 255 thresholds on a channel)."""
+    built from the union of the members' thresholds; ``view(i)`` is member i as a DeviceCascade whose rank tables are the
+    group's.  Raises NotImplementedError when the union does not fit (more than 255 thresholds on a channel).
+    Ownership runs one way -- view -> group -> member cascades -- so that a group nobody scans with any more is freed
+    by reference counting, at once (its __del__ issues hipFree calls: not something to leave to the cyclic collector)."""
 
     def __init__(self, cascades):
         lib = nat.load()
@@ -237,11 +244,12 @@ class RankGroup:
         h = C.c_void_p()
         nat.check(lib.wb_rankgroup_create(arr, len(self.members), C.byref(h)), "wb_rankgroup_create")
         self.handle = h
-        self.views = []
-        for i in range(len(self.members)):
-            v = C.c_void_p()
-            nat.check(lib.wb_rankgroup_model(h, i, C.byref(v)), "wb_rankgroup_model")
-            self.views.append(DeviceCascade._view(v, self))
+        self.token = object()              # what the engine's rank buffer is tagged with (DeviceCascade.rank_key)
+
+    def view(self, i):
+        v = C.c_void_p()
+        nat.check(self._lib.wb_rankgroup_model(self.handle, i, C.byref(v)), "wb_rankgroup_model")
+        return DeviceCascade._view(v, self)
 
     def __del__(self):
         try:
@@ -252,16 +260,25 @@ class RankGroup:
             pass
 
 
+class GroupViews:
+    """What rank_group hands out: the group's member views (stable objects: the engine keys its scan states by them)."""
+
+    def __init__(self, group):
+        self.group = group
+        self.members = group.members
+        self.views = [group.view(i) for i in range(len(group.members))]
+
+
 _GROUPS = {}
 
 
 def rank_group(cascades):
-    """The (cached) RankGroup of these cascades, or None when they cannot share a rank table."""
+    """The (cached) member views of the RankGroup of these cascades, or None when they cannot share a rank table."""
     key = tuple(id(dm) for dm in cascades)
     g = _GROUPS.get(key)
     if g is None or (g and any(a is not b for a, b in zip(g.members, cascades))):
         try:
-            g = RankGroup(cascades)
+            g = GroupViews(RankGroup(cascades))
         except NotImplementedError:
             g = False
         if len(_GROUPS) >= 8:

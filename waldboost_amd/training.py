@@ -49,6 +49,26 @@ class DTree:
             _REBINDS[0] += 1
         object.__setattr__(self, name, value)
 
+    # copy.copy / copy.deepcopy / pickle: NumPy copies (or unpickles) every view on its own, which would leave a tree whose
+    # `_blob` no longer shares memory with `threshold`, `feature`, ...: an in-place edit of the copy would then never reach
+    # content(), and Model.device_cascade would keep scanning with the stale GPU cascade.  So the state that travels is the
+    # five arrays (plus whatever else a caller hung on the tree), and the restored tree gets a block and views of its own.
+    def __getstate__(self):
+        state = {k: v for k, v in self.__dict__.items() if k not in ("_blob", "_dev", "node", "node_idx") and k not in _ARRAYS}
+        state["_arrays"] = {a: np.array(getattr(self, a)) for a in _ARRAYS}
+        return state
+
+    def __setstate__(self, state):
+        state = dict(state)
+        arrays = state.pop("_arrays", None)
+        if arrays is None:              # (a pickle written before this protocol existed: plain attribute dict)
+            arrays = {a: state.pop(a) for a in _ARRAYS}
+            for k in ("_blob", "_dev", "node", "node_idx"):
+                state.pop(k, None)
+        DTree.__init__(self, arrays["feature"], arrays["threshold"], arrays["left"], arrays["right"], arrays["prediction"])
+        for k, v in state.items():
+            object.__setattr__(self, k, v)
+
     def content(self):
         """The tree's current arrays as one bytes-like object (cheap: the private block itself unless an array
         was rebound)."""
