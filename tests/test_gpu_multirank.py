@@ -69,6 +69,68 @@ def test_detect_sharded_two_ranks_one_gpu():
     assert out[0][4] == out[1][4] and out[1][4][0] > 16     # rank 1 overflowed; both ranks grew to the same capacity
 
 
+def _chunk_worker(rank, world, port, q):
+    """Shards scanned in chunks (batch=2): rank 0 holds 4 images = two full chunks on two engines and two streams, rank 1
+    three = a full chunk and a remainder; device tensors; the call repeated (graph replays); no per-image statistics."""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import waldboost_amd as wb
+        from waldboost_amd.distributed import detect_sharded, shard_range
+        from waldboost_amd.synth import synth_image
+        here = os.path.dirname(os.path.abspath(__file__))
+        M = wb.load(os.path.join(here, "golden", "mixed_d2_T24.pb"))
+        lo, hi = shard_range(7, rank, world)
+        imgs = torch.from_numpy(np.stack([synth_image(200, 264, 900 + b) for b in range(lo, hi)])).cuda()
+        outs = []
+        for rep in range(3):
+            M.reset()
+            det, alive, total = detect_sharded(M, imgs, batch=2, per_image_alive=(rep == 0))
+            outs.append((None if det is None else det.tobytes(), None if alive is None else alive.tolist(), total.tolist(),
+                         (M.n_loc, M.n_weak)))
+        q.put((rank, outs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_detect_sharded_in_chunks_on_two_streams():
+    import waldboost_amd as wb
+    from waldboost_amd import _native as nat
+    from waldboost_amd.synth import synth_image
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_chunk_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    M = wb.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mixed_d2_T24.pb"))
+    imgs = np.stack([synth_image(200, 264, 900 + b) for b in range(7)])
+    ref = M.detect_batch_raw(imgs)
+    for rep in range(3):
+        det0, alive0, total0, cnt0 = out[0][rep]
+        det1, alive1, total1, cnt1 = out[1][rep]
+        assert det1 is None
+        got = np.frombuffer(det0, nat.DET_DTYPE)
+        assert np.array_equal(got["image"], ref["image"]) and np.array_equal(got["level"], ref["level"])
+        assert np.array_equal(got["r"], ref["r"].astype(np.uint16)) and np.array_equal(got["c"], ref["c"].astype(np.uint16))
+        assert np.array_equal(got["score"].view(np.uint32), ref["scores"].view(np.uint32))
+        assert np.array_equal(np.array(total0), ref["alive"].sum(axis=0)) and total0 == total1
+        assert cnt0 == cnt1 == (M.n_loc, M.n_weak)
+        if rep == 0:
+            assert np.array_equal(np.concatenate([np.array(alive0), np.array(alive1)]), ref["alive"])
+        else:
+            assert alive0 is None and alive1 is None
+
+
 def _edge_worker(rank, world, port, q):
     """float64 DEVICE tensors (held as float64 with a dtype code), an empty shard on rank 1, then images too small for
     any pyramid level: no rank may raise alone or block the other in a collective."""

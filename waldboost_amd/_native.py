@@ -113,6 +113,11 @@ def load():
     return lib
 
 
+def last_error():
+    """The thread's last error message of the native library (wb_last_error)."""
+    return load().wb_last_error().decode("utf-8", "replace")
+
+
 def check(rc, what=""):
     if rc == 0:
         return

@@ -10,6 +10,7 @@ csrc/*.hip.  Nothing here falls back to the CPU.
 """
 import contextlib
 import ctypes as C
+import logging
 import os
 import weakref
 
@@ -20,6 +21,7 @@ from .chanfunc import SPECS
 from .plan import PyramidPlan, N_CHANNELS
 
 _TORCH_DT = {}
+_log = logging.getLogger("waldboost_amd")
 
 
 @contextlib.contextmanager
@@ -217,8 +219,13 @@ class DeviceCascade:
             try:
                 if not self.specialize(chn_dtype):
                     self._jit_failed.add(chn_dtype)
-            except nat.NativeError:
-                self._jit_failed.add(chn_dtype)      # (stay on the generic kernel; the message is in wb_last_error)
+                    # (said once per cascade and tile kind: the generic kernel is ~10 % slower at batch 1)
+                    _log.info("cascade of %d stages, depth %d: no model-specialised kernel for this model (%s); staying on "
+                              "the generic tile kernel", self.n_stages, self.depth, nat.last_error())
+            except nat.NativeError as exc:
+                self._jit_failed.add(chn_dtype)      # (stay on the generic kernel)
+                _log.warning("cascade of %d stages, depth %d: building the model-specialised kernel failed, staying on the "
+                             "generic tile kernel (slower): %s", self.n_stages, self.depth, exc)
 
     def __del__(self):
         try:
