@@ -31,14 +31,14 @@ timeout -k 10 300 python3 bench.py --force-collective --no-cpu-baseline --steps 
 echo "bench lines done"
 fi
 if [[ $PART == *2* ]]; then
-S="--no-cpu-baseline --no-through-api --repeats 2"
+S="--no-cpu-baseline --no-through-api --no-config3 --repeats 2"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_default --output-format csv -- python3 bench.py $S > $O/stats_default.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_streams1 --output-format csv -- python3 bench.py $S --streams 1 > $O/stats_streams1.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_batch64 --output-format csv -- python3 bench.py $S --batch 64 --steps 10 --warmup 2 --pool 2 --streams 1 > $O/stats_batch64.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_cfg5 --output-format csv -- python3 tools/bench_cfg5.py > $O/stats_cfg5.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats_model_detect --output-format csv -- python3 tools/detect_breakdown.py > $O/stats_model_detect.log 2>&1 || exit 1
 echo "kernel stats done"
-T="--no-cpu-baseline --no-through-api --repeats 1 --steps 8 --warmup 2 --no-graph --streams 1"
+T="--no-cpu-baseline --no-through-api --no-config3 --repeats 1 --steps 8 --warmup 2 --no-graph --streams 1"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch --output-format csv -- python3 bench.py $T > $O/pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write --output-format csv -- python3 bench.py $T > $O/pmc_write.log 2>&1 || exit 1
 echo "traffic passes done"

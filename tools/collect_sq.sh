@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 O=$1; shift
 mkdir -p $O
 B=8
-ARGS="--no-cpu-baseline --no-through-api --steps 4 --warmup 1 --repeats 1 --no-graph --streams 1 --batch $B --pool 1 $*"
+ARGS="--no-cpu-baseline --no-through-api --no-config3 --steps 4 --warmup 1 --repeats 1 --no-graph --streams 1 --batch $B --pool 1 $*"
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_ANY"
 P2="SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 P3="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64"

@@ -5,7 +5,7 @@ set -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=$1; mkdir -p $O
-ARGS="--no-cpu-baseline --no-through-api --steps 3 --warmup 1 --repeats 1 --no-graph --streams 1 --batch 8 --pool 1 --stages 127"
+ARGS="--no-cpu-baseline --no-through-api --no-config3 --steps 3 --warmup 1 --repeats 1 --no-graph --streams 1 --batch 8 --pool 1 --stages 127"
 P="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_CVT SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CU_CYCLES"
 for v in "WB_CASC_DBG=2" "WB_CASC_DBG=4" "WB_CASC_DBG=8" "WB_CASC_DBG=16" "WB_CASC_DBG=32" "WB_CHAN_DBG=1" "WB_CHAN_DBG=2" "WB_CHAN_DBG=4" "X=0"; do
   export $v

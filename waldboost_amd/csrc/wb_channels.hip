@@ -86,6 +86,14 @@ __device__ inline uint8_t lds_byte_apart(const unsigned char *p) {
     asm volatile("" : "+v"(q));
     return *q;
 }
+// The same guarantee without the opaque pointer: a VOLATILE byte load is never merged with its neighbour, and -- unlike a
+// load through a laundered pointer, which needs an address register of its own -- a constant displacement still folds into
+// the instruction's offset field: the four tap bytes of a pixel (i0, i0 + 1 in two consecutive patch rows) come from ONE
+// address register (round 4: one vector add per tap pair less in the row loop).
+typedef const volatile __attribute__((address_space(3))) unsigned char *LdsVolBytePtr;
+__device__ __forceinline__ uint8_t lds_byte_vol(const unsigned char *patch, int off) {
+    return *((LdsVolBytePtr)patch + off);
+}
 
 // scipy's order-1 resample of one output pixel: fp64, taps and additions in NI_ZoomShift's order
 __device__ inline double resample_f64(double v00, double v01, double v10, double v11, const Tap &tr, const Tap &tc) {
@@ -113,10 +121,16 @@ template <> struct Src<uint8_t> {
     }
     // the same from the two rows' horizontal interpolations (a row's value is shared by the output rows that tap it)
     static __device__ bool fast_rows(float top, float bot, float wr0, float wr1, float &out) {
-        float t = __builtin_fmaf(bot, wr1, top * wr0);
-        float fl = floorf(t), fr = t - fl;
+        // (opaque to the SLP vectoriser: paired into v_pk_mul / v_pk_fma / v_pk_add the two rows of a pass cost more issue
+        // cycles than as plain fp32 instructions)
+        float t = hold(__builtin_fmaf(bot, wr1, hold(top * wr0)));
+        float fl = floorf(t), fr = hold(t - fl);
         out = fl;
-        return fabsf(fr - 0.5f) <= 0.5f - kEps;
+        return fabsf(hold(fr - 0.5f)) <= 0.5f - kEps;
+    }
+    static __device__ __forceinline__ float hold(float v) {
+        asm volatile("" : "+v"(v));
+        return v;
     }
     static __device__ double lo(uint32_t k) { return (double)k; }
     // fp64 result is clipped in fp64, then cast to uint8 by truncation
@@ -267,11 +281,13 @@ __device__ inline void project_int(float gx, float gy, const ChanArgs &a, float 
 constexpr float kSinHi = 0x1.6a09e6p-1f;
 constexpr float kSinLo = (float)(0x1.6a09e667f3bccp-1 - (double)kSinHi);
 __device__ inline void project_ordinary(float gx, float gy, const ChanArgs &, float *out) {
+    // (every result opaque to the SLP vectoriser: paired into v_pk_* the operations cost more issue cycles than plain ones,
+    // and a packed instruction takes no |x| modifier -- eight v_and per shrunk pixel materialised the absolute values)
     const float d1 = gx - gy, d3 = gx + gy;
     out[0] = fabsf(gx);
-    out[1] = fabsf(__builtin_fmaf(d1, kSinHi, d1 * kSinLo));
+    out[1] = fabsf(scalar_only(__builtin_fmaf(d1, kSinHi, scalar_only(d1 * kSinLo))));
     out[2] = fabsf(gy);
-    out[3] = fabsf(__builtin_fmaf(d3, kSinHi, d3 * kSinLo));
+    out[3] = fabsf(scalar_only(__builtin_fmaf(d3, kSinHi, scalar_only(d3 * kSinLo))));
 }
 
 // Tile geometry shared by the channel kernels: TU x TV outputs per workgroup of NT threads, shrink S
@@ -414,9 +430,12 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
         // dependent memory round trip in front of the patch loads of every workgroup)
         const bool strict = !ident && L.src_h > L.nh && L.src_w > L.nw;
         auto first_tap = [](int k, double step) { return (int)floor(((double)k + 0.5) * step - 0.5); };
-        r_lo = first_tap(yf, L.sy);
-        c_lo = first_tap(xf, L.sx);
-        const int r_hi = first_tap(yl, L.sy) + 1, c_hi = first_tap(xl, L.sx) + 1;
+        // (fp64 has no scalar unit: the four values are computed by the vector ALU in every lane alike -- said explicitly,
+        // so that everything derived from them, the staging loop's buffer descriptor included, stays in scalar registers)
+        r_lo = __builtin_amdgcn_readfirstlane(first_tap(yf, L.sy));
+        c_lo = __builtin_amdgcn_readfirstlane(first_tap(xf, L.sx));
+        const int r_hi = __builtin_amdgcn_readfirstlane(first_tap(yl, L.sy)) + 1;
+        const int c_hi = __builtin_amdgcn_readfirstlane(first_tap(xl, L.sx)) + 1;
         const int nrow = r_hi - r_lo + 1, nbyte = c_hi - c_lo + 1;
         staged = strict && nrow + 1 <= PROWS && nbyte + 8 <= PPITCH;
         WB_CSTAMP(1);
@@ -451,14 +470,24 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             for (int dw0 = 0; dw0 < ndw; dw0 += 64) {
                 int dw = dw0 + ln;
                 dw = dw < ndw ? dw : ndw - 1;
-                const T *col = src + c_lo + 4 * dw;
+                // a row's address = the patch origin (a buffer descriptor built from wave-uniform values: scalar registers)
+                // + the row's byte offset (a scalar: the instruction's soffset) + the lane's byte offset (a 32-bit vector
+                // register): the buffer load's own addressing mode -- no 64-bit vector multiply-add per row (round 4; plain
+                // pointer arithmetic is folded back into per-lane 64-bit pointers by the compiler)
+                const int voff = 4 * dw;
+                // (the origin is wave-uniform but the compiler cannot prove it and would wrap every load in a waterfall loop:
+                // its two halves go through readfirstlane)
+                const uint64_t origin = reinterpret_cast<uint64_t>(src + (int64_t)r_lo * L.src_w + c_lo);
+                const uint64_t origin_u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(origin >> 32)) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)origin);
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(origin_u), 0, 0x7fffffff, 0x00020000);
                 for (int r0 = wv; r0 < nrow; r0 += NW * UR) {
                     uint32_t v[UR];
                     int rr[UR];
 #pragma unroll
                     for (int k = 0; k < UR; ++k) {
                         rr[k] = r0 + NW * k < nrow ? r0 + NW * k : nrow - 1;
-                        v[k] = *reinterpret_cast<const u32u *>(col + (int64_t)(r_lo + rr[k]) * L.src_w);
+                        v[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rr[k] * L.src_w, 0);
                     }
 #pragma unroll
                     for (int k = 0; k < UR; ++k) pw[rr[k] * DWP + dw] = v[k];   // duplicates rewrite the same value
@@ -491,88 +520,80 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                 wc0f[c] = (float)tc[c].w0;
                 wc1f[c] = (float)tc[c].w1;
             }
-            // (fp64 row taps for the exact redo: lane l holds those of row l of the wave's strip -- trl -- fetched by readlane there)
-            // Each wave owns a strip of consecutive tile rows and walks it two rows per pass: every tap byte of
-            // the pass is requested before the first is used, and the rare exact redo is deferred behind all the
-            // fast-path arithmetic (one branch per pass; which pixels want it is kept as lane masks).  Consecutive
-            // output rows of a down-scale by less than 2 usually share a source row (the lower taps of row k are the
-            // upper taps of row k + 1): its horizontal interpolation -- two conversions, a multiply and an fma per
-            // pixel -- is then taken over instead of recomputed; which rows share is wave-uniform.
-#ifndef WB_CHAN_RB
-#define WB_CHAN_RB 2
-#endif
-            constexpr int RB = WB_CHAN_RB;
+            // Each wave owns a strip of consecutive tile rows and walks it RB rows per pass: every tap byte of the pass is
+            // requested before the first is used, and the exact redo (fp64, the lane-held fp64 taps -- lane l holds the row
+            // taps of row l of the strip: trl) is deferred behind all the fast-path arithmetic, one branch per pass.
+            // Consecutive output rows of a down-scale by less than 2 usually share a source row (the lower taps of row k are
+            // the upper taps of row k + 1): its horizontal interpolation is then taken over instead of read and computed
+            // again; which rows share is wave-uniform.
+            // Round 4: the passes are unrolled completely (a strip holds at most RSMAX rows), so nothing is carried
+            // around a loop back-edge -- the rolled loop spent 30 of its 88 vector instructions per pass on register moves
+            // (next pass's row entries, the previous row's interpolation and tap bytes) --, a pixel's four tap bytes hang
+            // off ONE address register (volatile loads, see lds_byte_vol), the tap bytes are not kept for the redo (it reads
+            // them again: a redo is rare per pixel), and nothing is left for the SLP vectoriser to pair.
+            constexpr int RB = 2;
+            constexpr int RSMAX = (RH + NW - 1) / NW, NPASS = (RSMAX + RB - 1) / RB;
             const int RS = (rh + NW - 1) / NW;
             const int k_lo = wave * RS, k_hi = k_lo + RS < rh ? k_lo + RS : rh;
-            float hprev[NCS];                     // horizontal interpolation of the patch row at byte offset o_prev,
-            uint8_t pb[NCS][2];                   // and its two tap bytes (the exact redo wants them)
+            float hprev[NCS];                     // horizontal interpolation of the patch row at byte offset o_prev
             int o_prev = -1;
 #pragma unroll
-            for (int c = 0; c < NCS; ++c) {
-                hprev[c] = 0.0f;
-                pb[c][0] = pb[c][1] = 0;
-            }
-            auto hlerp = [&](uint8_t x0, uint8_t x1, int c) { return __builtin_fmaf((float)x1, wc1f[c], (float)x0 * wc0f[c]); };
-            auto row_entry = [&](int k0, int rb) {
-                int k = k0 + rb;
-                k = k < k_hi ? k : k_hi - 1;
-                return rowtab[k];
+            for (int c = 0; c < NCS; ++c) hprev[c] = 0.0f;
+            auto hlerp = [&](uint8_t x0, uint8_t x1, int c) {
+                return scalar_only(__builtin_fmaf((float)x1, wc1f[c], scalar_only((float)x0 * wc0f[c])));
             };
-            float4 cur[RB];
+            float *Rrow = R + k_lo * RW + lane;   // this lane's first output of the strip
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) cur[rb] = row_entry(k_lo, rb);
-            for (int k0 = k_lo; k0 < k_hi; k0 += RB) {
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int k0 = k_lo + RB * ps;
+                if (k0 >= k_hi) break;                                          // wave-uniform
+                float4 ent[RB];
+                int o0[RB], av[RB][NCS];
+                bool shared[RB];
                 uint8_t b[RB][NCS][4];
-                float wr0[RB], wr1[RB];
-                int o0[RB], o0v[RB];
+                // every load of the pass first, unconditionally (a row past the strip's end repeats the last one; the upper
+                // tap pair is fetched even where the previous row's interpolation will stand in for it -- a branch around
+                // two byte loads made the compiler wait for them inside the branch, one LDS latency per row)
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
-                    o0v[rb] = __float_as_int(cur[rb].x);                       // vector copy: addresses
-                    o0[rb] = __builtin_amdgcn_readfirstlane(o0v[rb]);          // scalar copy: which rows share
-                    wr0[rb] = cur[rb].y;
-                    wr1[rb] = cur[rb].z;
-                    // (a00, a01) / (a10, a11) sit at i0, i0 + 1 of two consecutive patch rows; the upper pair is
-                    // not read again when it is the previous row's lower pair
-                    const int o_above = rb == 0 ? o_prev : o0[rb - 1] + PPITCH;
-                    if (o0[rb] != o_above) {                                    // wave-uniform
+                    int k = k0 + rb;
+                    k = k < k_hi ? k : k_hi - 1;
+                    ent[rb] = rowtab[k];                                        // wave-uniform address: a broadcast read
+                }
 #pragma unroll
-                        for (int c = 0; c < NCS; ++c) {
-                            const unsigned char *q = patch + (o0v[rb] + ci0[c]);
-                            b[rb][c][0] = q[0]; b[rb][c][1] = lds_byte_apart(q + 1);
-                        }
-                    }
+                for (int rb = 0; rb < RB; ++rb) {
+                    o0[rb] = __builtin_amdgcn_readfirstlane(__float_as_int(ent[rb].x));
+                    // (a00, a01) / (a10, a11) sit at i0, i0 + 1 of two consecutive patch rows; the upper pair's interpolation
+                    // is not computed again when it is the previous row's lower pair
+                    const int o_above = rb == 0 ? o_prev : o0[rb - 1] + PPITCH;
+                    shared[rb] = o0[rb] == o_above;
 #pragma unroll
                     for (int c = 0; c < NCS; ++c) {
-                        const unsigned char *q = patch + (o0v[rb] + ci0[c]);
-                        b[rb][c][2] = q[PPITCH]; b[rb][c][3] = lds_byte_apart(q + PPITCH + 1);
+                        av[rb][c] = ci0[c] + o0[rb];
+                        b[rb][c][0] = lds_byte_vol(patch, av[rb][c]);
+                        b[rb][c][1] = lds_byte_vol(patch, av[rb][c] + 1);
+                        b[rb][c][2] = lds_byte_vol(patch, av[rb][c] + PPITCH);
+                        b[rb][c][3] = lds_byte_vol(patch, av[rb][c] + PPITCH + 1);
                     }
                 }
-                // the next pass's row entries: requested here, used after this pass's arithmetic
-                float4 nxt[RB];
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) nxt[rb] = row_entry(k0 + RB, rb);
                 float out[RB][NCS];
                 bool need[RB][NCS];
                 bool redo = false;
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
-                    float top[NCS], bot[NCS];
-                    if (o0[rb] == o_prev) {                                     // wave-uniform
+                    float top[NCS];
+                    if (shared[rb]) {                                           // wave-uniform
 #pragma unroll
-                        for (int c = 0; c < NCS; ++c) {
-                            top[c] = hprev[c];
-                            b[rb][c][0] = pb[c][0]; b[rb][c][1] = pb[c][1];
-                        }
+                        for (int c = 0; c < NCS; ++c) top[c] = hprev[c];
                     } else {
 #pragma unroll
                         for (int c = 0; c < NCS; ++c) top[c] = hlerp(b[rb][c][0], b[rb][c][1], c);
                     }
 #pragma unroll
                     for (int c = 0; c < NCS; ++c) {
-                        bot[c] = hlerp(b[rb][c][2], b[rb][c][3], c);
-                        hprev[c] = bot[c];
-                        pb[c][0] = b[rb][c][2]; pb[c][1] = b[rb][c][3];
-                        need[rb][c] = !Src<T>::fast_rows(top[c], bot[c], wr0[rb], wr1[rb], out[rb][c]);
+                        const float bot = hlerp(b[rb][c][2], b[rb][c][3], c);
+                        hprev[c] = bot;
+                        need[rb][c] = !Src<T>::fast_rows(top[c], bot, ent[rb].y, ent[rb].z, out[rb][c]);
                         redo |= need[rb][c];
                     }
                     o_prev = o0[rb] + PPITCH;
@@ -598,12 +619,29 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                 }
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
-                    const int k = k0 + rb;
-                    if (k < k_hi) {
+                    if (k0 + rb < k_hi) {
 #pragma unroll
-                        for (int c = 0; c < NCS; ++c) R[k * RW + lane + 64 * c] = out[rb][c];
+                        for (int c = 0; c < NCS; ++c) Rrow[(RB * ps + rb) * RW + 64 * c] = out[rb][c];
                     }
-                    cur[rb] = nxt[rb];
+                }
+            }
+            // the RW % 64 right-most columns of the wave's own strip, one pixel per lane: row and column entries from the
+            // LDS tables, the four tap bytes off one address; coordinates and the fp64 taps only in the (rare) exact redo
+            if constexpr (LEFT > 0) {
+                const int nleft = (k_hi - k_lo) * LEFT;
+                for (int p = lane; p < nleft; p += 64) {
+                    const int kk = p / LEFT, q = p - kk * LEFT, k = k_lo + kk;
+                    const float4 er = rowtab[k], ec = rowtab[RH + q];
+                    const int o = __float_as_int(er.x) + __float_as_int(ec.x);
+                    const uint8_t a00 = lds_byte_vol(patch, o), a01 = lds_byte_vol(patch, o + 1);
+                    const uint8_t a10 = lds_byte_vol(patch, o + PPITCH), a11 = lds_byte_vol(patch, o + PPITCH + 1);
+                    float out = 0.0f;
+                    if (!Src<T>::fast((float)a00, (float)a01, (float)a10, (float)a11, er.y, er.z, ec.y, ec.z, out)) {
+                        const int y = tile_coord<REFLECT>(ry0 + k, L.nh), x = tile_coord<REFLECT>(rx0 + MAINW + q, L.nw);
+                        const Tap tr = rtap[y], tcl = ctap[x];
+                        out = Src<T>::finish(resample_f64((double)a00, (double)a01, (double)a10, (double)a11, tr, tcl), mn, mx, a.src_int);
+                    }
+                    R[k * RW + MAINW + q] = out;
                 }
             }
         }
@@ -666,27 +704,12 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
     }
     WB_CSTAMP(3);
     if constexpr (LEFT > 0) {
-        for (int p = tid; p < rh * LEFT; p += NT) {
+        // (a staged tile has done these columns wave by wave above)
+        for (int p = staged ? rh * LEFT : tid; p < rh * LEFT; p += NT) {
             const int k = p / LEFT, q = MAINW + p - k * LEFT;
             const int y = tile_coord<REFLECT>(ry0 + k, L.nh), x = tile_coord<REFLECT>(rx0 + q, L.nw);
             float out = 0.0f;
             bool ok = false;
-            if constexpr (sizeof(T) == 1) {
-                if (staged) {                        // the staged patch covers these columns too; taps from the LDS tables
-                    const unsigned char *patch = uni;
-                    const float4 er = rowtab[k], ec = rowtab[RH + q - MAINW];
-                    const int o0 = __float_as_int(er.x) + __float_as_int(ec.x);
-                    const uint8_t a00 = patch[o0], a01 = lds_byte_apart(patch + o0 + 1);
-                    const uint8_t a10 = patch[o0 + PPITCH], a11 = lds_byte_apart(patch + o0 + PPITCH + 1);
-                    ok = Src<T>::fast((float)a00, (float)a01, (float)a10, (float)a11, er.y, er.z, ec.y, ec.z, out);
-                    if (!ok) {
-                        const Tap tr = rtap[y], tc = ctap[x];
-                        out = Src<T>::finish(resample_f64((double)a00, (double)a01, (double)a10, (double)a11, tr, tc), mn, mx, a.src_int);
-                    }
-                    R[k * RW + q] = out;
-                    continue;
-                }
-            }
             const Tap tr = rtap[y], tc = ctap[x];
             const T *r0 = src + (int64_t)tr.i0 * L.src_w;
             const T *r1 = src + (int64_t)tr.i1 * L.src_w;
@@ -742,14 +765,14 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ?
     WB_CSTAMP(4);
     if (a.dbg & 1) return;
 
-    // ---- step 2: gradients -> 4 oriented channels -> shrink, one shrunk pixel per iteration
-    for (int p = tid; p < su_need * SV; p += NT) {
-        int i = p / SV, j = p - i * SV;
+    // ---- step 2: gradients -> 4 oriented channels -> shrink, one shrunk pixel per call
+    //      Rp: the pixel's (S + 2) x (S + 2) patch of R, Shp: where its shrunk value goes
+    auto shrunk_pixel = [&](const int ro, const int so) {     // (offsets, not pointers: R's alignment stays visible -- 8-byte reads)
         float pt[P][P];
 #pragma unroll
         for (int y = 0; y < P; ++y)
 #pragma unroll
-            for (int x = 0; x < P; ++x) pt[y][x] = R[(S * i + y) * RW + (S * j + x)];
+            for (int x = 0; x < P; ++x) pt[y][x] = R[ro + y * RW + x];
 
         float hc[S][P];   // vertical [1,2,1] pass at patch rows 1..S
         float hr[P][S];   // horizontal [1,2,1] pass at patch cols 1..S
@@ -787,16 +810,16 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ?
                 if constexpr (S == 1) {
                     o[k] = ch[0][0][k];
                 } else if constexpr (S == 2) {
-                    o[k] = (((ch[0][0][k] + ch[1][0][k]) + ch[0][1][k]) + ch[1][1][k]) * 0.25f;
+                    o[k] = scalar_only(scalar_only(scalar_only(scalar_only(ch[0][0][k] + ch[1][0][k]) + ch[0][1][k]) + ch[1][1][k]) * 0.25f);
                 } else {  // S == 4 (extension): avg_pool_2 applied twice
                     float q[2][2];
 #pragma unroll
                     for (int A = 0; A < 2; ++A)
 #pragma unroll
                         for (int B = 0; B < 2; ++B)
-                            q[A][B] = (((ch[2 * A][2 * B][k] + ch[2 * A + 1][2 * B][k]) + ch[2 * A][2 * B + 1][k]) +
-                                       ch[2 * A + 1][2 * B + 1][k]) * 0.25f;
-                    o[k] = (((q[0][0] + q[1][0]) + q[0][1]) + q[1][1]) * 0.25f;
+                            q[A][B] = scalar_only(scalar_only(scalar_only(scalar_only(ch[2 * A][2 * B][k] + ch[2 * A + 1][2 * B][k]) +
+                                                                  ch[2 * A][2 * B + 1][k]) + ch[2 * A + 1][2 * B + 1][k]) * 0.25f);
+                    o[k] = scalar_only(scalar_only(scalar_only(scalar_only(q[0][0] + q[1][0]) + q[0][1]) + q[1][1]) * 0.25f);
                 }
             }
         };
@@ -824,7 +847,35 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ?
         } else if constexpr (SEPARABLE) {
             flag_odd();
         }
-        Sh[p] = F4{o[0], o[1], o[2], o[3]};
+        Sh[so] = F4{o[0], o[1], o[2], o[3]};
+    };
+    // Tiles whose shrunk width is a wave or a little more (the 16 x 64 tiles: 66 columns): a wave owns whole rows, lane =
+    // column, so a pixel's LDS addresses are the previous round's plus a constant (no division by the width, no 64-bit
+    // multiply-add per pixel: round 4); the few columns beyond the 64th go to the last wave, which owns the fewest rows.
+    constexpr bool ROWMAP = SV >= 64 && SV - 64 <= 8 && NT % 64 == 0;
+    if constexpr (ROWMAP) {
+        constexpr int NWV = NT / 64, XC = SV - 64;
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        int ro = S * (wave * RW + lane), so = wave * SV + lane;
+#pragma nounroll
+        for (int i = wave; i < su_need; i += NWV) {                               // wave-uniform trip count
+            shrunk_pixel(ro, so);
+            ro += NWV * S * RW;
+            so += NWV * SV;
+        }
+        if constexpr (XC > 0) {
+            if (wave == NWV - 1) {
+                for (int p = lane; p < su_need * XC; p += 64) {
+                    const int i = p / XC, j = 64 + p - i * XC;
+                    shrunk_pixel(S * (i * RW + j), i * SV + j);
+                }
+            }
+        }
+    } else {
+        for (int p = tid; p < su_need * SV; p += NT) {
+            const int i = p / SV, j = p - i * SV;
+            shrunk_pixel(S * (i * RW + j), p);
+        }
     }
     // rank tables of the model (12 KiB, L2-resident): requested before the barrier, parked in R -- dead once every
     // thread has left step 2 -- right behind it
