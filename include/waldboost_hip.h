@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define WB_ABI_VERSION 6
+#define WB_ABI_VERSION 7
 
 #define WB_OK 0
 #define WB_ERR_INVALID (-1)     /* bad argument / malformed model */
@@ -218,6 +218,27 @@ int wb_channels_launch(void *stream, const void *img, int64_t img_stride, const 
                        const WbTap *taps, int channel_func, int shrink, int smooth, const double *cs_sn,
                        void *chn, int64_t chn_stride, const WbModel *rank_model, uint8_t *rank,
                        int64_t rank_stride);
+
+/* The same launch with a per-tile side table (ABI 7): patches = dev WbTilePatch[n_tiles], entry i for tiles[i] -- the
+ * source patch that tile stages in LDS for its resample, as wb_channels_tile_patches computes it on the HOST from the
+ * library's own tile geometry (the level plan and its tiles are host data anyway, channels.py:124-131).  With the table a
+ * workgroup starts its patch loads right behind its tile record instead of behind four chains of fp64 arithmetic that
+ * every workgroup of a level would repeat.  patches = NULL: exactly wb_channels_launch.  Results are identical either way. */
+typedef struct WbTilePatch {
+    int32_t r_lo;    /* first source row / column of the patch in the level's octave                               */
+    int32_t c_lo;
+    uint16_t rows;   /* source rows r_lo .. r_lo + rows - 1; 0 = this tile stages no patch (an identity level, an   */
+    uint16_t bytes;  /* up-scale, a patch beyond the LDS budget): it takes the kernel's other paths                 */
+    uint32_t pad;
+} WbTilePatch;       /* 16 bytes */
+int wb_channels_tile_patches(int channel_func, int shrink, int smooth, const WbLevel *levels_host, int n_levels,
+                             const WbTile *tiles_host, int n_tiles, WbTilePatch *out_host);
+int wb_channels_launch_x(void *stream, const void *img, int64_t img_stride, const void *oct,
+                         int64_t oct_stride, int dtype, int batch, const WbLevel *levels, int n_levels,
+                         const WbTile *tiles, int n_tiles, const uint32_t *minmax, int n_oct,
+                         const WbTap *taps, int channel_func, int shrink, int smooth, const double *cs_sn,
+                         void *chn, int64_t chn_stride, const WbModel *rank_model, uint8_t *rank,
+                         int64_t rank_stride, const WbTilePatch *patches);
 
 /* The pyramid around a channel function this library has no kernel for (channels.py:119,136 calls whatever callable
  * channel_opts["channels"] holds -- the caller runs it, between these two):

@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(nat.SYMBOLS), (declared ^ set(nat.SYMBOLS))
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.wb_abi_version() == nat.WB_ABI_VERSION == 6
+    assert lib.wb_abi_version() == nat.WB_ABI_VERSION == 7
     assert lib.wb_last_error() is not None
 
 
@@ -248,6 +248,48 @@ def test_copied_and_unpickled_models_keep_following_in_place_edits(monkeypatch, 
     d1 = N.device_cascade()
     assert d1 is not d0 and d1.snapshot[5][0] == 9
     assert M.classifier[5].threshold[0] != 9                  # the original is untouched
+
+
+@pytest.mark.parametrize("shape,shrink,n_per_oct,func", [((1080, 1920), 2, 8, "WB_CHN_GRAD_HIST"), ((480, 640), 1, 8, "WB_CHN_GRAD_HIST"),
+                                                        ((540, 960), 4, 12, "WB_CHN_GRAD_HIST"), ((200, 264), 2, 8, "WB_CHN_GRAD_HIST_4_U1")])
+def test_tile_patch_table_covers_every_tap_of_its_tile(shape, shrink, n_per_oct, func):
+    """wb_channels_tile_patches (host, no GPU): the source patch of every staged tile must hold every tap (i0, i0 + 1 on both
+    axes, scipy's zoom taps: channels.py:132) of every resized pixel the tile computes, and stay inside the kernel's LDS
+    budget; identity levels and up-scaling levels stage nothing."""
+    lib = nat.load()
+    fid = getattr(nat, func)
+    p = PyramidPlan(shape[0], shape[1], shrink, n_per_oct, 1, chan_func=fid)
+    table, _ = p.level_table()
+    tiles = np.ascontiguousarray(p.chan_tiles())
+    out = np.zeros(tiles.size, nat.PATCH_DTYPE)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.wb_channels_tile_patches(fid, shrink, 1, vp(table), p.n_levels, vp(tiles), tiles.size, vp(out)) == 0
+    tu, tv = C.c_int(), C.c_int()
+    assert lib.wb_channels_tile(fid, shrink, C.byref(tu), C.byref(tv)) == 0
+    tu, tv, S = tu.value, tv.value, shrink
+    rw = S * (tv + 2) + 2
+    n_staged = 0
+    for t, o in zip(tiles[::7], out[::7]):
+        lv = p.levels[int(t["level"])]
+        ident = lv["h"] == lv["nh"] and lv["w"] == lv["nw"]
+        if ident or lv["h"] <= lv["nh"] or lv["w"] <= lv["nw"]:
+            assert o["rows"] == 0 and o["bytes"] == 0
+            continue
+        if o["rows"] == 0:
+            continue                                    # (a patch beyond the LDS budget: the kernel's direct path)
+        n_staged += 1
+        u0, v0 = int(t["ty"]) * tu, int(t["tx"]) * tv
+        vrows = min(lv["u"] - u0, tu) if func == "WB_CHN_GRAD_HIST" else tu
+        ry0, rx0, rh = S * (u0 - 1) - 1, S * (v0 - 1) - 1, S * (vrows + 2) + 2
+        ys = np.clip(np.arange(ry0, ry0 + rh), 0, lv["nh"] - 1)
+        xs = np.clip(np.arange(rx0, rx0 + rw), 0, lv["nw"] - 1)
+        ty, tx = PyramidPlan.axis_taps(lv["h"], lv["nh"])[ys], PyramidPlan.axis_taps(lv["w"], lv["nw"])[xs]
+        assert ty["i0"].min() >= o["r_lo"] and ty["i1"].max() <= o["r_lo"] + o["rows"] - 1
+        assert tx["i0"].min() >= o["c_lo"] and tx["i1"].max() <= o["c_lo"] + o["bytes"] - 1
+        assert (ty["i1"] == ty["i0"] + 1).all() and (tx["i1"] == tx["i0"] + 1).all()
+        assert o["r_lo"] + o["rows"] <= lv["h"] and o["c_lo"] + o["bytes"] <= lv["w"]
+    assert n_staged > 0
+    assert lib.wb_channels_tile_patches(nat.WB_CHN_GRAD_MAG, shrink, 1, vp(table), p.n_levels, vp(tiles), tiles.size, vp(out)) == nat.WB_ERR_UNSUPPORTED
 
 
 def test_boxes_container():

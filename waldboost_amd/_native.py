@@ -19,7 +19,7 @@ WB_ERR_INVALID, WB_ERR_HIP, WB_ERR_UNSUPPORTED = -1, -2, -3
 WB_DET_SHARDS = 64
 WB_DTYPE_I64, WB_DTYPE_U64, WB_DTYPE_BOOL, WB_DTYPE_F16 = 9, 10, 11, 12
 WB_CHN_GRAD_HIST, WB_CHN_GRAD_HIST_4_U1, WB_CHN_GRAD_MAG_U1, WB_CHN_GRAD_MAG = 0, 1, 2, 3
-WB_ABI_VERSION = 6
+WB_ABI_VERSION = 7
 
 # numpy mirrors of the ABI structs (sizes asserted against the header's comments)
 LEVEL_DTYPE = np.dtype([
@@ -28,8 +28,10 @@ LEVEL_DTYPE = np.dtype([
     ("sy", "<f8"), ("sx", "<f8")], align=True)
 TAP_DTYPE = np.dtype([("i0", "<i4"), ("i1", "<i4"), ("w0", "<f8"), ("w1", "<f8")], align=True)
 TILE_DTYPE = np.dtype([("level", "<i4"), ("ty", "<u2"), ("tx", "<u2")], align=True)
+PATCH_DTYPE = np.dtype([("r_lo", "<i4"), ("c_lo", "<i4"), ("rows", "<u2"), ("bytes", "<u2"), ("pad", "<u4")], align=True)   # WbTilePatch
 DET_DTYPE = np.dtype([("image", "<i4"), ("level", "<i4"), ("r", "<u2"), ("c", "<u2"), ("score", "<f4")], align=True)
 assert LEVEL_DTYPE.itemsize == 64 and TILE_DTYPE.itemsize == 8 and DET_DTYPE.itemsize == 16 and TAP_DTYPE.itemsize == 24
+assert PATCH_DTYPE.itemsize == 16
 
 
 class WbModelInfo(C.Structure):
@@ -52,6 +54,10 @@ SYMBOLS = {
     "wb_channels_launch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int,
                                      _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P, C.c_int64,
                                      _P, _P, C.c_int64]),
+    "wb_channels_launch_x": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int,
+                                       _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P, C.c_int64,
+                                       _P, _P, C.c_int64, _P]),
+    "wb_channels_tile_patches": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P]),
     "wb_resize_level_launch": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, _P]),
     "wb_pool_smooth_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "wb_grad_hist_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double), _P]),

@@ -39,6 +39,7 @@ struct ChanArgs {
     // optional second output of channels_kernel: the pixels as threshold ranks of one model (WB_DTYPE_RANK8)
     uint8_t *rank;       // [u][v][4] bytes per level, same element offsets as chn; nullptr = none
     int64_t rank_stride;
+    const WbTilePatch *patches;   // optional (uint8 images): per tile, the source patch it stages (wb_channels_tile_patches)
     const uint4 *rank_lut;   // WbModel::bin_lut_dev: float S[4][256], then uint8 base[4][WB_BIN_CELLS]
     int rank_iters;
     float rank_k[4], rank_b[4];
@@ -324,7 +325,7 @@ template <int S_, int TU_, int TV_, bool SMOOTH_, int NT_ = 256> struct TileGeom
 //      clamped to the level = the 'reflect' halo of convolve1d for a 1-pixel border.
 //      The RW % 64 right-most columns are done afterwards, one pixel per thread.
 //      Ends without a barrier: the caller synchronises before reading R.
-__device__ inline int reflect_index(int i, int n) {      // scipy 'reflect': (d c b a | a b c d | d c b a)
+__host__ __device__ inline int reflect_index(int i, int n) {      // scipy 'reflect': (d c b a | a b c d | d c b a)
     const int period = 2 * n;
     i %= period;
     if (i < 0) i += period;
@@ -333,7 +334,7 @@ __device__ inline int reflect_index(int i, int n) {      // scipy 'reflect': (d 
 
 // Coordinate i of a tile (possibly outside its level of n pixels) -> the level pixel it stands for: clamped (= the
 // 'reflect' halo of a 1-pixel border: the gradient kernels) or reflected (grad_mag's 6-pixel halo).
-template <bool REFLECT> __device__ __forceinline__ int tile_coord(int i, int n) {
+template <bool REFLECT> __host__ __device__ __forceinline__ int tile_coord(int i, int n) {
     if constexpr (REFLECT)
         return reflect_index(i, n);
     else
@@ -342,7 +343,7 @@ template <bool REFLECT> __device__ __forceinline__ int tile_coord(int i, int n) 
 
 // ... and bounds [lo_out, hi_out] on the level pixels the coordinates lo..hi stand for (conservative under reflection:
 // they only size the staged source patch).
-template <bool REFLECT> __device__ __forceinline__ void tile_coord_range(int lo, int hi, int n, int &lo_out, int &hi_out) {
+template <bool REFLECT> __host__ __device__ __forceinline__ void tile_coord_range(int lo, int hi, int n, int &lo_out, int &hi_out) {
     if constexpr (!REFLECT) {
         lo_out = tile_coord<false>(lo, n);
         hi_out = tile_coord<false>(hi, n);
@@ -361,13 +362,36 @@ template <bool REFLECT> __device__ __forceinline__ void tile_coord_range(int lo,
     }
 }
 
+// The source patch a uint8 tile stages: rows r_lo .. r_lo + nrow - 1, bytes c_lo .. c_lo + nbyte - 1 of the level's octave,
+// for tile rows ry0 .. ry0 + rh - 1 and columns rx0 .. rx0 + RW - 1; false when the tile does not stage one.  Strict
+// down-scale on both axes: every tap pair is (i0, i0 + 1), no mirroring (plan.axis_taps), and the extents follow from the
+// first and last coordinate's i0 = floor((k + 0.5) * step - 0.5) -- the host's own fp64 expression for the tap table.
+// The SAME function runs on the host (wb_channels_tile_patches: IEEE fp64 on both sides, no contraction) and, without a
+// table, in every workgroup.
+template <typename G, bool REFLECT>
+__host__ __device__ __forceinline__ bool tile_patch_extent(const WbLevel &L, int ry0, int rx0, int rh, int &r_lo, int &c_lo, int &nrow,
+                                                           int &nbyte) {
+    int yf, yl, xf, xl;
+    tile_coord_range<REFLECT>(ry0, ry0 + rh - 1, L.nh, yf, yl);
+    tile_coord_range<REFLECT>(rx0, rx0 + G::RW - 1, L.nw, xf, xl);
+    const bool ident = (L.src_h == L.nh) && (L.src_w == L.nw);
+    const bool strict = !ident && L.src_h > L.nh && L.src_w > L.nw;
+    auto first_tap = [](int k, double step) { return (int)floor(((double)k + 0.5) * step - 0.5); };
+    r_lo = first_tap(yf, L.sy);
+    c_lo = first_tap(xf, L.sx);
+    const int r_hi = first_tap(yl, L.sy) + 1, c_hi = first_tap(xl, L.sx) + 1;
+    nrow = r_hi - r_lo + 1;
+    nbyte = c_hi - c_lo + 1;
+    return strict && nrow + 1 <= G::PROWS && nbyte + 8 <= G::PPITCH;
+}
+
 template <typename T, typename G, bool REFLECT = false>
 __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &L, const T *src, const double mn,
                                               const double mx, const int ry0, const int rx0, const int rh, float *R,
                                               unsigned char *uni, float4 *rowtab, const int tid) {
     // rh <= RH: the tile rows that are needed (a tile on the bottom edge of its level uses fewer): wave-uniform, the
     // strips below are cut from it
-    constexpr int RH = G::RH, RW = G::RW, PROWS = G::PROWS, PPITCH = G::PPITCH, NT = G::NT, NW = G::NW;
+    constexpr int RH = G::RH, RW = G::RW, PPITCH = G::PPITCH, NT = G::NT, NW = G::NW;
     const Tap *__restrict__ rtap = a.taps + L.tap_off;      // row taps [nh], then column taps [nw]
     const Tap *__restrict__ ctap = rtap + L.nh;
     constexpr int NCS = RW / 64, MAINW = NCS * 64, LEFT = RW - MAINW;
@@ -421,23 +445,25 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
 #pragma unroll
     for (int c = 0; c < NCS; ++c) tcs[c] = trl;
     if constexpr (sizeof(T) == 1) {
-        int yf, yl, xf, xl;
-        tile_coord_range<REFLECT>(ry0, ry0 + rh - 1, L.nh, yf, yl);
-        tile_coord_range<REFLECT>(rx0, rx0 + RW - 1, L.nw, xf, xl);
-        // strict down-scale on both axes: every tap pair is (i0, i0 + 1), no mirroring (plan.axis_taps), and the
-        // patch extents follow from the first and last coordinate's i0 = floor((k + 0.5) * step - 0.5) -- the host's
-        // own fp64 expression (the tap table holds the same numbers, but loading them here put one more
-        // dependent memory round trip in front of the patch loads of every workgroup)
-        const bool strict = !ident && L.src_h > L.nh && L.src_w > L.nw;
-        auto first_tap = [](int k, double step) { return (int)floor(((double)k + 0.5) * step - 0.5); };
-        // (fp64 has no scalar unit: the four values are computed by the vector ALU in every lane alike -- said explicitly,
-        // so that everything derived from them, the staging loop's buffer descriptor included, stays in scalar registers)
-        r_lo = __builtin_amdgcn_readfirstlane(first_tap(yf, L.sy));
-        c_lo = __builtin_amdgcn_readfirstlane(first_tap(xf, L.sx));
-        const int r_hi = __builtin_amdgcn_readfirstlane(first_tap(yl, L.sy)) + 1;
-        const int c_hi = __builtin_amdgcn_readfirstlane(first_tap(xl, L.sx)) + 1;
-        const int nrow = r_hi - r_lo + 1, nbyte = c_hi - c_lo + 1;
-        staged = strict && nrow + 1 <= PROWS && nbyte + 8 <= PPITCH;
+        // the patch extents: from the host's per-tile table when there is one (wb_channels_launch_x: a scalar load right
+        // behind the tile record), else computed here -- four chains of fp64 arithmetic in front of every patch load
+        int nrow, nbyte;
+        if (a.patches) {
+            const WbTilePatch tp = a.patches[blockIdx.x];
+            r_lo = tp.r_lo;
+            c_lo = tp.c_lo;
+            nrow = tp.rows;
+            nbyte = tp.bytes;
+            staged = nrow != 0;
+        } else {
+            // (fp64 has no scalar unit: the values are computed by the vector ALU in every lane alike -- said explicitly,
+            // so that everything derived from them, the staging loop's buffer descriptor included, stays in scalar registers)
+            staged = tile_patch_extent<G, REFLECT>(L, ry0, rx0, rh, r_lo, c_lo, nrow, nbyte);
+            r_lo = __builtin_amdgcn_readfirstlane(r_lo);
+            c_lo = __builtin_amdgcn_readfirstlane(c_lo);
+            nrow = __builtin_amdgcn_readfirstlane(nrow);
+            nbyte = __builtin_amdgcn_readfirstlane(nbyte);
+        }
         WB_CSTAMP(1);
         // the taps the resample below wants -- a lane's column taps, the row taps of the wave's strip (lane l: its row l), the taps of the
         // RW % 64 right-most columns -- are requested HERE, in front of the patch loads: behind the staging barrier each
@@ -464,7 +490,6 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             constexpr int DWP = PPITCH / 4;                       // dwords per patch row
             const int ndw = (nbyte + 1 + 3) / 4;                  // + the (i0 + 1) neighbour of the last column
             uint32_t *pw = reinterpret_cast<uint32_t *>(uni);
-            typedef uint32_t __attribute__((aligned(1))) u32u;
             constexpr int UR = WB_CHAN_UR;
             const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
             for (int dw0 = 0; dw0 < ndw; dw0 += 64) {
@@ -1639,13 +1664,79 @@ extern "C" int wb_channel_func_info(int channel_func, int *n_channels, int *chn_
     return WB_ERR_INVALID;
 }
 
+// Per tile, the source patch it stages (WbTilePatch): the kernels' own extent function, on the host, with the geometry of
+// the kernel that channel_func / shrink / smooth select.
+namespace {
+template <typename G, bool FULL_ROWS>
+void fill_patches(const WbLevel *levels, const WbTile *tiles, int n_tiles, WbTilePatch *out) {
+    for (int i = 0; i < n_tiles; ++i) {
+        const WbTile &t = tiles[i];
+        const WbLevel &L = levels[t.level];
+        const int u0 = t.ty * G::TU, v0 = t.tx * G::TV;
+        const int ry0 = G::S * (u0 - G::HS) - 1, rx0 = G::S * (v0 - G::HS) - 1;
+        // (channels_kernel computes only the rows a tile on the bottom edge of its level needs; the uint8 kernels all RH)
+        const int vrows = L.u - u0 < G::TU ? L.u - u0 : G::TU;
+        const int rh = FULL_ROWS ? G::RH : G::S * (vrows + 2 * G::HS) + 2;
+        int r_lo, c_lo, nrow, nbyte;
+        const bool staged = tile_patch_extent<G, false>(L, ry0, rx0, rh, r_lo, c_lo, nrow, nbyte);
+        WbTilePatch &o = out[i];
+        o.r_lo = staged ? r_lo : 0;
+        o.c_lo = staged ? c_lo : 0;
+        o.rows = staged ? (uint16_t)nrow : 0;
+        o.bytes = staged ? (uint16_t)nbyte : 0;
+        o.pad = 0;
+    }
+}
+template <bool FULL_ROWS>
+int fill_patches_for(int shrink, bool smooth, bool big, const WbLevel *levels, const WbTile *tiles, int n_tiles, WbTilePatch *out) {
+#define WB_FP(S, TU, TV)                                                                  \
+    if (smooth) fill_patches<TileGeom<S, TU, TV, true>, FULL_ROWS>(levels, tiles, n_tiles, out); \
+    else fill_patches<TileGeom<S, TU, TV, false>, FULL_ROWS>(levels, tiles, n_tiles, out);
+    switch (shrink) {
+        case 1: WB_FP(1, 16, 64) return WB_OK;
+        case 2: if (big) { WB_FP(2, 32, 64) } else { WB_FP(2, 16, 64) } return WB_OK;
+        case 4: WB_FP(4, 8, 32) return WB_OK;
+    }
+#undef WB_FP
+    wb_set_error("wb_channels_tile_patches: shrink=%d unsupported (1, 2; 4 as an extension)", shrink);
+    return WB_ERR_UNSUPPORTED;
+}
+}  // namespace
+
+extern "C" int wb_channels_tile_patches(int channel_func, int shrink, int smooth, const WbLevel *levels_host, int n_levels,
+                                        const WbTile *tiles_host, int n_tiles, WbTilePatch *out_host) {
+    WB_REQUIRE(levels_host && tiles_host && out_host && n_levels >= 1 && n_tiles >= 0, "wb_channels_tile_patches: null pointer / empty plan");
+    for (int i = 0; i < n_tiles; ++i)
+        WB_REQUIRE(tiles_host[i].level >= 0 && tiles_host[i].level < n_levels, "wb_channels_tile_patches: tile %d names level %d of %d", i,
+                   tiles_host[i].level, n_levels);
+    if (channel_func == WB_CHN_GRAD_HIST)
+        return fill_patches_for<false>(shrink, smooth != 0, tile32(), levels_host, tiles_host, n_tiles, out_host);
+    if (channel_func == WB_CHN_GRAD_HIST_4_U1 || channel_func == WB_CHN_GRAD_MAG_U1)
+        return fill_patches_for<true>(shrink, smooth != 0, false, levels_host, tiles_host, n_tiles, out_host);
+    wb_set_error("wb_channels_tile_patches: channel function %d takes no patch table", channel_func);
+    return WB_ERR_UNSUPPORTED;
+}
+
 extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_stride, const void *oct,
                                   int64_t oct_stride, int dtype, int batch, const WbLevel *levels,
                                   int n_levels, const WbTile *tiles, int n_tiles, const uint32_t *minmax,
                                   int n_oct, const WbTap *taps, int channel_func, int shrink, int smooth,
                                   const double *cs_sn, void *chn, int64_t chn_stride, const WbModel *rank_model,
                                   uint8_t *rank, int64_t rank_stride) {
+    return wb_channels_launch_x(stream, img, img_stride, oct, oct_stride, dtype, batch, levels, n_levels, tiles, n_tiles, minmax,
+                                n_oct, taps, channel_func, shrink, smooth, cs_sn, chn, chn_stride, rank_model, rank, rank_stride,
+                                nullptr);
+}
+
+extern "C" int wb_channels_launch_x(void *stream, const void *img, int64_t img_stride, const void *oct,
+                                    int64_t oct_stride, int dtype, int batch, const WbLevel *levels,
+                                    int n_levels, const WbTile *tiles, int n_tiles, const uint32_t *minmax,
+                                    int n_oct, const WbTap *taps, int channel_func, int shrink, int smooth,
+                                    const double *cs_sn, void *chn, int64_t chn_stride, const WbModel *rank_model,
+                                    uint8_t *rank, int64_t rank_stride, const WbTilePatch *patches) {
     WB_REQUIRE(img && levels && tiles && minmax && taps && (chn || rank), "wb_channels_launch: null pointer");
+    WB_REQUIRE(!patches || (dtype == WB_DTYPE_U8 && channel_func != WB_CHN_GRAD_MAG),
+               "wb_channels_launch_x: the patch table goes with uint8 images and the gradient-histogram kernels");
     WB_REQUIRE(!rank == !rank_model, "wb_channels_launch: rank and rank_model go together");
     WB_REQUIRE(!rank || channel_func == WB_CHN_GRAD_HIST, "wb_channels_launch: ranks are written for grad_hist channels only");
     WB_REQUIRE(!rank || rank_model->bin_ok, "wb_channels_launch: this model has no rank tables (wb_model_info: rank_ok)");
@@ -1672,6 +1763,7 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
     a.rank_stride = rank_stride;
     a.rank_lut = nullptr;
     a.rank_iters = 0;
+    a.patches = patches;
     if (rank) {
         a.rank_lut = reinterpret_cast<const uint4 *>(rank_model->bin_lut_dev);
         a.rank_iters = rank_model->bin_iters;

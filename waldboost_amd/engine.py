@@ -414,6 +414,7 @@ class PyramidEngine:
         tiles = p.chan_tiles()
         self.n_chan_tiles = int(tiles.size)
         self.chan_tiles = torch.from_numpy(tiles.view(np.uint8).copy()).to(dev) if tiles.size else None
+        self.chan_patches = self._tile_patches(tiles)
         # (16 spare elements: the cascade's uint8 tile load fetches 16-byte groups that may run past a level row)
         self._chn_flat = torch.zeros(self.batch * self.chn_stride + 16, dtype=_torch_dtype(self.spec.dtype), device=dev)
         self.chn = self._chn_flat[: self.batch * self.chn_stride].view(self.batch, self.chn_stride)
@@ -438,6 +439,23 @@ class PyramidEngine:
                 raise NotImplementedError("channel functions on a bare image take uint8 or float32 arrays")
             self.minmax[:, :, 0] = int(np.array([~np.uint32(lo)], np.uint32).view(np.int32)[0])   # word 0 stores max(~key), see csrc/wb_octaves.hip
             self.minmax[:, :, 1] = int(np.array([hi], np.uint32).view(np.int32)[0])
+
+    def _tile_patches(self, tiles):
+        """The per-tile patch table of wb_channels_launch_x for a tile list (uint8 images, the gradient-histogram kernels):
+        filled on the host by the library with its own tile geometry, uploaded once.  None: the kernels compute the extents."""
+        import torch
+        if self.wb_dtype != nat.WB_DTYPE_U8 or not tiles.size or os.environ.get("WB_NO_TILE_PATCHES"):
+            return None
+        p = self.plan
+        tiles = np.ascontiguousarray(tiles)
+        out = np.zeros(tiles.size, nat.PATCH_DTYPE)
+        rc = self.lib.wb_channels_tile_patches(self.spec.func_id, p.shrink, p.smooth, self.level_np.ctypes.data_as(C.c_void_p),
+                                               p.n_levels, tiles.ctypes.data_as(C.c_void_p), int(tiles.size),
+                                               out.ctypes.data_as(C.c_void_p))
+        if rc == nat.WB_ERR_UNSUPPORTED:
+            return None
+        nat.check(rc, "wb_channels_tile_patches")
+        return torch.from_numpy(out.view(np.uint8).copy()).to(self.dev)
 
     def _alloc_ctrl(self, alive_words):
         """(Re)allocate the control block with room for `alive_words` statistics words; the views into it follow."""
@@ -569,15 +587,16 @@ class PyramidEngine:
         if rank_dm is not None and self.rank is None:
             self._rank_flat = torch.zeros(self.batch * self.chn_stride + 16, dtype=torch.uint8, device=self.dev)
             self.rank = self._rank_flat[: self.batch * self.chn_stride].view(self.batch, self.chn_stride)
-        nat.check(self.lib.wb_channels_launch(nat.stream_ptr(), nat.ptr(self.img), p.H * p.W, nat.ptr(self.oct),
-                                              p.oct_total, self.wb_dtype, self.batch, nat.ptr(self.levels),
-                                              p.n_levels, nat.ptr(self.chan_tiles), self.n_chan_tiles,
-                                              nat.ptr(self.minmax), max(p.n_oct, 1), nat.ptr(self.taps),
-                                              self.spec.func_id, p.shrink, p.smooth,
-                                              self.cs_sn.ctypes.data_as(C.POINTER(C.c_double)),
-                                              nat.ptr(self.chn if floats or rank_dm is None else None), self.chn_stride,
-                                              rank_dm.handle if rank_dm is not None else None,
-                                              nat.ptr(self.rank if rank_dm is not None else None), self.chn_stride),
+        nat.check(self.lib.wb_channels_launch_x(nat.stream_ptr(), nat.ptr(self.img), p.H * p.W, nat.ptr(self.oct),
+                                                p.oct_total, self.wb_dtype, self.batch, nat.ptr(self.levels),
+                                                p.n_levels, nat.ptr(self.chan_tiles), self.n_chan_tiles,
+                                                nat.ptr(self.minmax), max(p.n_oct, 1), nat.ptr(self.taps),
+                                                self.spec.func_id, p.shrink, p.smooth,
+                                                self.cs_sn.ctypes.data_as(C.POINTER(C.c_double)),
+                                                nat.ptr(self.chn if floats or rank_dm is None else None), self.chn_stride,
+                                                rank_dm.handle if rank_dm is not None else None,
+                                                nat.ptr(self.rank if rank_dm is not None else None), self.chn_stride,
+                                                nat.ptr(self.chan_patches)),
                   "wb_channels_launch")
         self.rank_owner = rank_dm.rank_key if rank_dm is not None else None      # whose ranks self.rank holds (None: stale)
 
@@ -592,17 +611,18 @@ class PyramidEngine:
             self._level_tiles = []
             for k in range(p.n_levels):
                 sel = np.ascontiguousarray(tiles[tiles["level"] == k])
-                self._level_tiles.append((int(sel.size), torch.from_numpy(sel.view(np.uint8).copy()).to(self.dev) if sel.size else None))
-        n, tiles_d = self._level_tiles[l]
+                self._level_tiles.append((int(sel.size), torch.from_numpy(sel.view(np.uint8).copy()).to(self.dev) if sel.size else None,
+                                          self._tile_patches(sel)))
+        n, tiles_d, patches_d = self._level_tiles[l]
         if n == 0:
             return
-        nat.check(self.lib.wb_channels_launch(nat.stream_ptr(), nat.ptr(self.img), p.H * p.W, nat.ptr(self.oct),
-                                              p.oct_total, self.wb_dtype, self.batch, nat.ptr(self.levels),
-                                              p.n_levels, nat.ptr(tiles_d), n,
-                                              nat.ptr(self.minmax), max(p.n_oct, 1), nat.ptr(self.taps),
-                                              self.spec.func_id, p.shrink, p.smooth,
-                                              self.cs_sn.ctypes.data_as(C.POINTER(C.c_double)),
-                                              nat.ptr(self.chn), self.chn_stride, None, None, 0),
+        nat.check(self.lib.wb_channels_launch_x(nat.stream_ptr(), nat.ptr(self.img), p.H * p.W, nat.ptr(self.oct),
+                                                p.oct_total, self.wb_dtype, self.batch, nat.ptr(self.levels),
+                                                p.n_levels, nat.ptr(tiles_d), n,
+                                                nat.ptr(self.minmax), max(p.n_oct, 1), nat.ptr(self.taps),
+                                                self.spec.func_id, p.shrink, p.smooth,
+                                                self.cs_sn.ctypes.data_as(C.POINTER(C.c_double)),
+                                                nat.ptr(self.chn), self.chn_stride, None, None, 0, nat.ptr(patches_d)),
                   "wb_channels_launch")
 
 
