@@ -10,10 +10,12 @@ from waldboost_amd.synth import synth_image
 lib = nat.load()
 lib.wb_debug_channel_stamps.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-e = PyramidEngine(1080, 1920, np.uint8, 2, 8, 1, batch=B)
-e.load_images(np.stack([synth_image(1080, 1920, s) for s in range(B)]))
+CFG5 = "cfg5" in sys.argv                                      # BASELINE configs[4]: 4K, shrink 4, 12 per octave
+H, W, SHRINK, NPO = (2160, 3840, 4, 12) if CFG5 else (1080, 1920, 2, 8)
+e = PyramidEngine(H, W, np.uint8, SHRINK, NPO, 1, batch=B)
+e.load_images(np.stack([synth_image(H, W, s) for s in range(B)]))
 import waldboost_amd as wb
-M = wb.load(os.path.join(ROOT, "tests/golden/models/cfg2_d2_T128.pb"))
+M = wb.load(os.path.join(ROOT, "tests/golden/models/cfg5_d2_T256.pb" if CFG5 else "tests/golden/models/cfg2_d2_T128.pb"))
 dm = M.device_cascade()
 RANKS = len(sys.argv) > 2 and sys.argv[2] == "ranks"          # the fused detection form: ranks only
 e.run_channels(dm if RANKS else None, floats=not RANKS); torch.cuda.synchronize()

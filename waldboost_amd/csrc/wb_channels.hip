@@ -13,6 +13,7 @@
 // Replaces reference channels.py:127-146 (per-level body of channel_pyramid), :40-52
 // (grad_hist), :16-21 (gradients), :55-64 (avg_pool_2), :78-90 (smooth).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "wb_common.h"
 
@@ -64,6 +65,14 @@ __device__ unsigned long long g_chan_stamps[WB_CSTAMP_WGS * WB_CSTAMP_SLOTS];
 
 #ifndef WB_CHAN_UR
 #define WB_CHAN_UR 8
+#endif
+// shrink 4 / uint8: R as bytes (1) or floats (0: the round-3 form, three workgroups per CU), and the waves per SIMD the
+// register allocator is held to
+#ifndef WB_CHAN_S4_BYTES
+#define WB_CHAN_S4_BYTES 1
+#endif
+#ifndef WB_CHAN_S4_WAVES
+#define WB_CHAN_S4_WAVES (WB_CHAN_S4_BYTES ? 5 : 3)
 #endif
 typedef WbTap Tap;   // one axis of the bilinear resample (scipy NI_ZoomShift, order 1), host-built table
 
@@ -385,10 +394,19 @@ __host__ __device__ __forceinline__ bool tile_patch_extent(const WbLevel &L, int
     return strict && nrow + 1 <= G::PROWS && nbyte + 8 <= G::PPITCH;
 }
 
-template <typename T, typename G, bool REFLECT = false>
+// RT: how R holds a resized pixel -- float, or (uint8 images only: the pixels are integers 0..255) one byte, rows padded to
+// whole dwords: a quarter of the LDS, for the price of one conversion per store here and one per read in the caller.
+template <typename RT, int RW> struct RPitch { static constexpr int value = sizeof(RT) == 1 ? ((RW + 3) & ~3) : RW; };
+
+template <typename T, typename G, bool REFLECT = false, typename RT = float>
 __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &L, const T *src, const double mn,
-                                              const double mx, const int ry0, const int rx0, const int rh, float *R,
+                                              const double mx, const int ry0, const int rx0, const int rh, RT *R,
                                               unsigned char *uni, float4 *rowtab, const int tid) {
+    static_assert(sizeof(RT) == 4 || sizeof(T) == 1, "byte R holds uint8 pixels");
+    constexpr int RP = RPitch<RT, G::RW>::value;             // R's row pitch in elements
+    auto rput = [&](int idx, float v) {
+        if constexpr (sizeof(RT) == 1) R[idx] = (RT)(int)v; else R[idx] = v;
+    };
     // rh <= RH: the tile rows that are needed (a tile on the bottom edge of its level uses fewer): wave-uniform, the
     // strips below are cut from it
     constexpr int RH = G::RH, RW = G::RW, PPITCH = G::PPITCH, NT = G::NT, NW = G::NW;
@@ -418,13 +436,17 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                 e = e < NE ? e : NE - 1;                              // (duplicates rewrite the same values)
                 const int k = e / RWD, d = e - k * RWD;
                 v[i] = *reinterpret_cast<const u32u *>(src + (int64_t)(ry0 + k) * L.src_w + rx0 + 4 * d);
-                at[i] = k * RW + 4 * d;
+                at[i] = k * RP + 4 * d;
             }
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                float2 *dst = reinterpret_cast<float2 *>(R + at[i]);
-                dst[0] = make_float2((float)(v[i] & 0xffu), (float)((v[i] >> 8) & 0xffu));
-                if (at[i] % RW + 2 < RW) dst[1] = make_float2((float)((v[i] >> 16) & 0xffu), (float)(v[i] >> 24));
+                if constexpr (sizeof(RT) == 1) {
+                    *reinterpret_cast<uint32_t *>(R + at[i]) = v[i];        // (the source bytes ARE the pixels; rows are whole dwords)
+                } else {
+                    float2 *dst = reinterpret_cast<float2 *>(R + at[i]);
+                    dst[0] = make_float2((float)(v[i] & 0xffu), (float)((v[i] >> 8) & 0xffu));
+                    if (at[i] % RW + 2 < RW) dst[1] = make_float2((float)((v[i] >> 16) & 0xffu), (float)(v[i] >> 24));
+                }
             }
             WB_CSTAMP(1);
             WB_CSTAMP(2);
@@ -567,7 +589,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             auto hlerp = [&](uint8_t x0, uint8_t x1, int c) {
                 return scalar_only(__builtin_fmaf((float)x1, wc1f[c], scalar_only((float)x0 * wc0f[c])));
             };
-            float *Rrow = R + k_lo * RW + lane;   // this lane's first output of the strip
+            const int rrow = k_lo * RP + lane;    // this lane's first output of the strip
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int k0 = k_lo + RB * ps;
@@ -646,7 +668,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                 for (int rb = 0; rb < RB; ++rb) {
                     if (k0 + rb < k_hi) {
 #pragma unroll
-                        for (int c = 0; c < NCS; ++c) Rrow[(RB * ps + rb) * RW + 64 * c] = out[rb][c];
+                        for (int c = 0; c < NCS; ++c) rput(rrow + (RB * ps + rb) * RP + 64 * c, out[rb][c]);
                     }
                 }
             }
@@ -666,7 +688,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                         const Tap tr = rtap[y], tcl = ctap[x];
                         out = Src<T>::finish(resample_f64((double)a00, (double)a01, (double)a10, (double)a11, tr, tcl), mn, mx, a.src_int);
                     }
-                    R[k * RW + MAINW + q] = out;
+                    rput(k * RP + MAINW + q, out);
                 }
             }
         }
@@ -722,7 +744,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                             out = Src<T>::finish(resample_f64((double)v00[rb][c], (double)v01[rb][c], (double)v10[rb][c],
                                                               (double)v11[rb][c], tr[rb], tc[c]), mn, mx, a.src_int);
                     }
-                    if (k < rh) R[k * RW + lane + 64 * c] = out;
+                    if (k < rh) rput(k * RP + lane + 64 * c, out);
                 }
             }
         }
@@ -745,7 +767,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
                 if (!ok) ok = Src<T>::fast((float)a00, (float)a01, (float)a10, (float)a11, (float)tr.w0, (float)tr.w1,
                                            (float)tc.w0, (float)tc.w1, out);
             if (!ok) out = Src<T>::finish(resample_f64((double)a00, (double)a01, (double)a10, (double)a11, tr, tc), mn, mx, a.src_int);
-            R[k * RW + q] = out;
+            rput(k * RP + q, out);
         }
     }
 }
@@ -754,14 +776,26 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
 // allocator may trade that occupancy for a few more registers -- measured: 138 VGPRs, 3 waves per SIMD, +17 % time)
 // (NT threads per workgroup: 256 for the 16 x 64 tile, 512 for the 32 x 64 tile -- the same 4 waves per SIMD either way)
 template <typename T, int S, int TU, int TV, bool SMOOTH, bool FAST, int NT>
-__global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ? 3 : 1) : 4) void channels_kernel(ChanArgs a) {
+__global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ? WB_CHAN_S4_WAVES : 1) : 4) void channels_kernel(ChanArgs a) {
     using G = TileGeom<S, TU, TV, SMOOTH, NT>;
     constexpr int HS = G::HS, SV = G::SV, RH = G::RH, RW = G::RW, P = G::P;
     constexpr int PATCH_BYTES = sizeof(T) == 1 ? G::PATCH_BYTES : 0;
     constexpr int UNI_BYTES = G::SH_BYTES > PATCH_BYTES ? G::SH_BYTES : PATCH_BYTES;
-    constexpr int R_FLOATS = RH * RW > WB_BIN_LUT_BYTES / 4 ? RH * RW : WB_BIN_LUT_BYTES / 4;   // (R later holds the rank tables)
-    __shared__ __attribute__((aligned(16))) float R[R_FLOATS];
+    // Shrink 4, uint8 images (round 4): R holds the resized pixels as BYTES (they are integers 0..255) -- 5.9 KB instead of
+    // 23 KB, and the rank tables are parked behind the shrunk tile in `uni` (the dead source patch) instead of in R: 31 KB of
+    // LDS per workgroup = five per CU instead of three.  The kernel at this shrink is latency-bound (16 resized pixels per
+    // output: three workgroups kept the vector ALUs 42 % busy), so residency is what it wants; the price is one conversion
+    // per R store and 36 per shrunk pixel's patch read.
+    constexpr bool RBYTES = S == 4 && sizeof(T) == 1 && WB_CHAN_S4_BYTES;
+    using RT = typename std::conditional<RBYTES, uint8_t, float>::type;
+    constexpr int RP = RPitch<RT, RW>::value;
+    constexpr bool LUT_IN_UNI = RBYTES;
+    static_assert(!LUT_IN_UNI || UNI_BYTES >= ((G::SH_BYTES + 15) & ~15) + WB_BIN_LUT_BYTES, "the rank tables fit behind the shrunk tile");
+    constexpr int R_BYTES = LUT_IN_UNI ? RH * RP : (RH * RW * 4 > WB_BIN_LUT_BYTES ? RH * RW * 4 : WB_BIN_LUT_BYTES);   // (float R later holds the rank tables)
+    __shared__ __attribute__((aligned(16))) unsigned char Rraw[R_BYTES];
+    RT *R = reinterpret_cast<RT *>(Rraw);
     __shared__ __attribute__((aligned(16))) unsigned char uni[UNI_BYTES];
+    unsigned char *lut_lds = LUT_IN_UNI ? uni + ((G::SH_BYTES + 15) & ~15) : Rraw;
     __shared__ uint32_t odd_values;      // set when a shrunk value lies outside the exact-sum range (see step 3)
     __shared__ float4 rowtab[sizeof(T) == 1 ? RH + RW % 64 : 1];   // row taps of the tile, taps of the RW % 64 last columns (uint8 images, staged patch)
     F4 *Sh = reinterpret_cast<F4 *>(uni);
@@ -785,7 +819,7 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ?
     const int vrows = L.u - u0 < TU ? L.u - u0 : TU;
     const int su_need = vrows + 2 * HS, rh_need = S * su_need + 2;
     WB_CSTAMP(0);
-    resample_tile<T, G>(a, L, src, mn, mx, ry0, rx0, rh_need, R, uni, rowtab, tid);
+    resample_tile<T, G, false, RT>(a, L, src, mn, mx, ry0, rx0, rh_need, R, uni, rowtab, tid);
     __syncthreads();
     WB_CSTAMP(4);
     if (a.dbg & 1) return;
@@ -794,10 +828,26 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ?
     //      Rp: the pixel's (S + 2) x (S + 2) patch of R, Shp: where its shrunk value goes
     auto shrunk_pixel = [&](const int ro, const int so) {     // (offsets, not pointers: R's alignment stays visible -- 8-byte reads)
         float pt[P][P];
+        if constexpr (RBYTES) {
+            // six bytes per patch row = two aligned dwords (the patch starts at column S * j = 4 j of a dword-padded row)
+            static_assert(P == 6 && RP % 4 == 0, "shrink-4 patch rows");
 #pragma unroll
-        for (int y = 0; y < P; ++y)
+            for (int y = 0; y < P; ++y) {
+                const uint32_t *w = reinterpret_cast<const uint32_t *>(R + ro + y * RP);
+                const uint32_t w0 = w[0], w1 = w[1];
+                pt[y][0] = (float)(w0 & 0xffu);
+                pt[y][1] = (float)((w0 >> 8) & 0xffu);
+                pt[y][2] = (float)((w0 >> 16) & 0xffu);
+                pt[y][3] = (float)(w0 >> 24);
+                pt[y][4] = (float)(w1 & 0xffu);
+                pt[y][5] = (float)((w1 >> 8) & 0xffu);
+            }
+        } else {
 #pragma unroll
-            for (int x = 0; x < P; ++x) pt[y][x] = R[ro + y * RW + x];
+            for (int y = 0; y < P; ++y)
+#pragma unroll
+                for (int x = 0; x < P; ++x) pt[y][x] = R[ro + y * RP + x];
+        }
 
         float hc[S][P];   // vertical [1,2,1] pass at patch rows 1..S
         float hr[P][S];   // horizontal [1,2,1] pass at patch cols 1..S
@@ -881,25 +931,25 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ?
     if constexpr (ROWMAP) {
         constexpr int NWV = NT / 64, XC = SV - 64;
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        int ro = S * (wave * RW + lane), so = wave * SV + lane;
+        int ro = S * (wave * RP + lane), so = wave * SV + lane;
 #pragma nounroll
         for (int i = wave; i < su_need; i += NWV) {                               // wave-uniform trip count
             shrunk_pixel(ro, so);
-            ro += NWV * S * RW;
+            ro += NWV * S * RP;
             so += NWV * SV;
         }
         if constexpr (XC > 0) {
             if (wave == NWV - 1) {
                 for (int p = lane; p < su_need * XC; p += 64) {
                     const int i = p / XC, j = 64 + p - i * XC;
-                    shrunk_pixel(S * (i * RW + j), i * SV + j);
+                    shrunk_pixel(S * (i * RP + j), i * SV + j);
                 }
             }
         }
     } else {
         for (int p = tid; p < su_need * SV; p += NT) {
             const int i = p / SV, j = p - i * SV;
-            shrunk_pixel(S * (i * RW + j), p);
+            shrunk_pixel(S * (i * RP + j), p);
         }
     }
     // rank tables of the model (12 KiB, L2-resident): requested before the barrier, parked in R -- dead once every
@@ -915,7 +965,7 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ?
     }
     __syncthreads();
     if (ranks) {
-        uint4 *lut = reinterpret_cast<uint4 *>(R);
+        uint4 *lut = reinterpret_cast<uint4 *>(lut_lds);
         lut[tid] = lut0;
         if (NT == 256 || tid < 256) lut[tid + NT] = lut1;
         if (NT == 256) lut[tid + 512] = lut2;
@@ -1004,8 +1054,8 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ?
     if (ranks) {
         // the same pixels as threshold ranks, one dword per pixel (wb_common.h: wb_bin_rank)
         __syncthreads();                                      // the tables are in R
-        const float *Sthr = reinterpret_cast<const float *>(R);
-        const uint8_t *base = reinterpret_cast<const uint8_t *>(R) + 4 * WB_BIN_SLOTS * 4;
+        const float *Sthr = reinterpret_cast<const float *>(lut_lds);
+        const uint8_t *base = reinterpret_cast<const uint8_t *>(lut_lds) + 4 * WB_BIN_SLOTS * 4;
         uint32_t *rout = reinterpret_cast<uint32_t *>(a.rank + (int64_t)b * a.rank_stride + L.chn_off);
         const int K = a.rank_iters;
         // all RPT x 4 values of the thread advance together: every step is RPT * 4 independent LDS lookups (one
