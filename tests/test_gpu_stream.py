@@ -210,3 +210,46 @@ def test_stream_with_more_detections_than_one_read_back_holds(batch, monkeypatch
         assert np.array_equal(ref[0].get(), o["boxes"]) and np.array_equal(ref[0].get_field("scores").view(np.uint32), o["scores"].view(np.uint32))
     finally:
         E._ENGINES.clear()
+
+
+def test_detect_takes_page_locked_arrays_and_torch_tensors():
+    """An extension of the reference's host-ndarray input (model.py:149): page-locked arrays are uploaded asynchronously,
+    torch tensors (host, page-locked, device) are taken as they are -- same Boxes as from a plain ndarray."""
+    import torch
+    M = wb.load(os.path.join(GOLDEN, "mixed_d2_T24.pb"))
+    img = synth_image(240, 320, 5)
+    ref = M.detect(img)
+    pinned_t = torch.from_numpy(img).pin_memory()
+    for src in (pinned_t.numpy(), pinned_t, torch.from_numpy(img), torch.from_numpy(img).cuda()):
+        for _ in range(3):                                   # (eager, captured, replayed)
+            got = M.detect(src)
+            assert np.array_equal(got.get(), ref.get()) and np.array_equal(got.get_field("scores"), ref.get_field("scores"))
+    with pytest.raises(TypeError):
+        M.detect([[0, 1], [2, 3]])
+    with pytest.raises(ValueError):
+        M.detect(torch.zeros((2, 3, 4), dtype=torch.uint8))
+    f32 = torch.from_numpy(synth_image(240, 320, 6, np.float32)).cuda()
+    a, b = M.detect(f32), M.detect(f32.cpu().numpy())
+    assert np.array_equal(a.get(), b.get()) and len(a) == len(b)
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_detect_stream_from_one_reused_page_locked_buffer(batch):
+    """A producer that decodes every frame into the SAME page-locked buffer: the asynchronous upload must have left the
+    buffer before the stream asks for the next frame."""
+    import torch
+    M = wb.load(os.path.join(GOLDEN, "mixed_d2_T24.pb"))
+    frames = [synth_image(200, 264, 40 + i) for i in range(11)]
+    ref = [M.detect(f) for f in frames]
+    buf = torch.empty((200, 264), dtype=torch.uint8).pin_memory()
+    view = buf.numpy()
+
+    def producer():
+        for f in frames:
+            view[...] = f                                    # overwrites what the previous frame was uploaded from
+            yield view
+
+    out = list(M.detect_stream(producer(), lanes=3, batch=batch))
+    assert len(out) == len(ref)
+    for a, b in zip(out, ref):
+        assert np.array_equal(a.get(), b.get()) and np.array_equal(a.get_field("scores"), b.get_field("scores"))

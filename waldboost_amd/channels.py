@@ -21,10 +21,13 @@ from . import engine as _engine
 from .chanfunc import SPECS, ChannelSpec  # noqa: F401
 
 
-def _validate_image(image):
+def _validate_image(image, allow_tensor=False):
     # reference channels.py:104-108
+    # allow_tensor (Model.detect / detect_stream only -- an extension: the reference takes host ndarrays): a 2-D torch
+    # tensor, on the host (page-locked: uploaded asynchronously) or already on the GPU
     if not isinstance(image, np.ndarray):
-        raise TypeError("Image must be numpy array")
+        if not (allow_tensor and type(image).__module__.startswith("torch") and hasattr(image, "data_ptr")):
+            raise TypeError("Image must be numpy array")
     if image.ndim != 2:
         raise ValueError("Image must have 2 dimensions")
 

@@ -246,7 +246,9 @@ __global__ __launch_bounds__(256) void octaves_block_kernel(const T *img, int64_
     T *nxt = from_regs ? bufA : bufB;
     int side = from_regs ? OB / 2 : OB;  // side of `cur`
     const int kmax = n_oct - 1 < OB_LEVELS ? n_oct - 1 : OB_LEVELS;
-    for (int k = from_regs ? 2 : 1; k <= kmax; ++k) {
+    int k = from_regs ? 2 : 1;
+    for (; k <= kmax; ++k) {
+        if ((side >> 1) * (side >> 1) <= 64) break;       // the small octaves: one wave, no barriers (below)
         const int ns = side >> 1;
         const int oh = d.h[k], ow = d.w[k];
         const int oy0 = y0 >> k, ox0 = x0 >> k;
@@ -277,6 +279,47 @@ __global__ __launch_bounds__(256) void octaves_block_kernel(const T *img, int64_
         cur = nxt;
         nxt = t;
         side = ns;
+    }
+    // ---- the octaves of at most 64 pixels per block (the last four of a 128 x 128 block): wave 0 alone walks them, lane =
+    //      pixel -- LDS serves a wave's accesses in order, so a level's reads see the previous level's writes without a
+    //      workgroup barrier; the other waves go straight to the final reduction (at batch 1 the kernel is ONE round of
+    //      workgroups whose length is this serial chain: four barriers and four sweeps of 256 threads over a handful of
+    //      pixels less)
+    if (tid < 64) {
+        for (; k <= kmax; ++k) {
+            const int ns = side >> 1;
+            const int oh = d.h[k], ow = d.w[k];
+            const int oy0 = y0 >> k, ox0 = x0 >> k;
+            T *dst = obase + d.off[k];
+            nlo = 0u;
+            hi = 0u;
+            if (tid < ns * ns) {
+                const int r = tid / ns, c = tid - r * ns;
+                const T *p0 = cur + (2 * r) * side + 2 * c;
+                const T v = pool4<T>(p0[0], p0[side], p0[1], p0[side + 1]);
+                nxt[r * ns + c] = v;
+                const int y = oy0 + r, x = ox0 + c;
+                if (y < oh && x < ow) {
+                    dst[(int64_t)y * ow + x] = v;
+                    const uint32_t key = PixKey<T>::key(v);
+                    nlo = ~key;
+                    hi = key;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 1; j <= OB_LEVELS; ++j)
+                if (j == k) {
+                    pmm[2 * j] = nlo;
+                    pmm[2 * j + 1] = hi;
+                }
+            T *t = cur;
+            cur = nxt;
+            nxt = t;
+            side = ns;
+        }
     }
     // ---- min/max of all octaves: wave reduction, exchange through LDS, then lane j commits value j
     const int nval = 2 * (kmax + 1);

@@ -166,15 +166,17 @@ class Model:
     def detect_raw(self, image, _full=True):
         """detect() with everything the parity tests compare: boxes, scores, (level, r, c),
         alive[level, stage]; updates n_loc / n_weak.  (_full=False: boxes and scores only -- what detect() returns.)"""
-        _channels._validate_image(image)
+        _channels._validate_image(image, allow_tensor=True)
         shrink, n_per_oct, smooth, spec = _channels.read_opts(self.channel_opts, allow_callable=True)
         if spec is None:
+            if not isinstance(image, np.ndarray):
+                image = image.cpu().numpy()                 # (a caller's own channel function takes host arrays)
             return self._detect_raw_levelwise(image)
         m, n, Cc = self.shape
         assert Cc == spec.n_channels, f"Invalid number of channels. Expected {Cc} given {spec.n_channels}."
-        H, W = image.shape
+        H, W = (int(x) for x in image.shape)
         dm = self.device_cascade()
-        eng = _engine.get_engine(H, W, image.dtype, shrink, n_per_oct, smooth, 1, channels=spec)
+        eng = _engine.get_engine(H, W, _engine.array_dtype(image), shrink, n_per_oct, smooth, 1, channels=spec)
         T = len(self)
         if eng.plan.n_levels == 0:
             return dict(boxes=np.empty((0, 4), "f"), scores=np.empty(0, "f"), level=np.empty(0, np.int32),
@@ -317,9 +319,10 @@ class Model:
 
         try:
             for image in images:
-                _channels._validate_image(image)
-                H, W = image.shape
-                key = (H, W, np.dtype(image.dtype).str, shrink, n_per_oct, smooth, spec.key, K)
+                _channels._validate_image(image, allow_tensor=True)
+                H, W = (int(x) for x in image.shape)
+                idt = _engine.array_dtype(image)
+                key = (H, W, idt.str, shrink, n_per_oct, smooth, spec.key, K)
                 dm = self.device_cascade()
                 if fill is not None and (fill[0] != key or fill[3] is not dm):
                     send(fill)                                # (another shape, or the model changed: the batch goes as it is)
@@ -336,7 +339,7 @@ class Model:
                     busy = {id(it[0]) for it in pending}
                     lane = next((ln for ln in group if id(ln[0]) not in busy), None)
                     if lane is None:
-                        lane = (_engine.PyramidEngine(H, W, image.dtype, shrink, n_per_oct, smooth, K, channels=spec),
+                        lane = (_engine.PyramidEngine(H, W, idt, shrink, n_per_oct, smooth, K, channels=spec),
                                 torch.cuda.Stream())
                         group.append(lane)
                     eng, stream = lane
@@ -360,6 +363,10 @@ class Model:
                     fill = None
                 if len(pending) >= lanes:
                     yield from finish(pending.pop(0))
+                # an image uploaded asynchronously from the caller's page-locked buffer: the copy has left that buffer
+                # before the iterable is asked for its next image (a decoder may write into the same buffer again); by
+                # now the scan is enqueued and an older lane has been collected, so this wait is over before it starts
+                eng.wait_upload()
             if fill is not None:
                 send(fill)
                 fill = None
