@@ -813,7 +813,8 @@ def main():
                        "batch_per_gpu": B, "levels": plan.n_levels, "windows_per_image": n_loc,
                        "launch": "eager" if args.no_graph else ("one hipGraph replay per stream and timed region of K steps" if region is not None
                                                                 else "hipGraph replay per step"), "only": args.only,
-                       "channels_in_hbm": "uint8 threshold ranks of the cascade (WB_DTYPE_RANK8)" if fused else spec.dtype.name,
+                       "channels_in_hbm": (("16-bit threshold ranks of the cascade (WB_DTYPE_RANK16)" if dm.rank_dtype == nat.WB_DTYPE_RANK16
+                                            else "uint8 threshold ranks of the cascade (WB_DTYPE_RANK8)") if fused else spec.dtype.name),
                        "streams": n_streams, "pool": P,
                        "warm": f"{n_warm} untimed region(s) of {args.steps} steps right before the timed ones (--warm-ms {args.warm_ms:g})",
                        "warm_steps_untimed": args.warmup + n_warm * (args.steps if region is not None else max(args.warmup, args.steps)),

@@ -65,6 +65,11 @@ extern "C" {
  * model.  Available when the model has 4 channels and at most 254 distinct thresholds per channel
  * (WbModelInfo.rank_ok). */
 #define WB_DTYPE_RANK8 2
+/* The same in TWO bytes per element (ABI 7): for models with up to 1020 distinct thresholds per channel -- long soft
+ * cascades (reference __init__.py:230-269 appends stages without bound), deep trees -- whose channels would otherwise
+ * stay float32.  65535 marks a NaN pixel.  Written by wb_channels_launch_x(rank_dtype = WB_DTYPE_RANK16), read by
+ * wb_cascade_launch(chn_dtype = WB_DTYPE_RANK16); available when WbModelInfo.rank16_ok. */
+#define WB_DTYPE_RANK16 13
 /* Image buffers only: the other dtypes the reference's channel_pyramid accepts (channels.py:122 keeps
  * image.dtype).  All of them are held as float64 elements (exact for these integer types); the code tells the
  * octave kernel how avg_pool_2's adds wrap (integers wrap modulo 2^bits in the array's dtype, channels.py:61-64)
@@ -164,7 +169,8 @@ typedef struct WbModelInfo {
     int32_t tile_cols;
     int32_t lds_bytes;  /* dynamic LDS per workgroup of the cascade kernel         */
     int32_t rank_ok;    /* 1 = the model has rank tables (WB_DTYPE_RANK8 channels)  */
-    int32_t specialized; /* bit 0: a model-specialised kernel is loaded for uint8 channels, bit 1: for ranks */
+    int32_t specialized; /* bit 0: a model-specialised kernel is loaded for uint8 channels, bit 1: for ranks, bit 2: for 16-bit ranks */
+    int32_t rank16_ok;   /* 1 = the model has 16-bit rank tables (WB_DTYPE_RANK16 channels) */
 } WbModelInfo;
 
 int wb_abi_version(void);
@@ -238,7 +244,9 @@ int wb_channels_launch_x(void *stream, const void *img, int64_t img_stride, cons
                          const WbTile *tiles, int n_tiles, const uint32_t *minmax, int n_oct,
                          const WbTap *taps, int channel_func, int shrink, int smooth, const double *cs_sn,
                          void *chn, int64_t chn_stride, const WbModel *rank_model, uint8_t *rank,
-                         int64_t rank_stride, const WbTilePatch *patches);
+                         int64_t rank_stride, const WbTilePatch *patches, int rank_dtype);
+/* rank_dtype: WB_DTYPE_RANK8 (what wb_channels_launch writes) or WB_DTYPE_RANK16 -- `rank` is then uint16 [u][v][4] per
+ * level (rank_stride and the level offsets count ELEMENTS, as for every channel buffer), 8-byte aligned. */
 
 /* The pyramid around a channel function this library has no kernel for (channels.py:119,136 calls whatever callable
  * channel_opts["channels"] holds -- the caller runs it, between these two):
@@ -288,7 +296,7 @@ int wb_model_info(const WbModel *model, WbModelInfo *info);
 
 /* Compile (hiprtc, a couple of seconds the first time; afterwards from the cache directory $WB_JIT_CACHE, default
  * ~/.cache/waldboost_amd) and load the model-specialised tile kernel for one kind of byte tile: chn_dtype
- * WB_DTYPE_RANK8 or WB_DTYPE_U8.  The model's stage records -- feature offsets, thresholds (model.py:62-67,
+ * WB_DTYPE_RANK8, WB_DTYPE_RANK16 or WB_DTYPE_U8.  The model's stage records -- feature offsets, thresholds (model.py:62-67,
  * training.py:24-31), leaf values and theta -- are compile-time constants in it.  wb_cascade_launch uses it from then
  * on for that dtype; results are bit-identical to the generic kernel's.  WB_ERR_UNSUPPORTED for float32 channels and
  * for models on the node-walk kernel; a failed compilation leaves the model on the generic kernel. */
@@ -309,6 +317,8 @@ int wb_rankgroup_destroy(WbRankGroup *group);
 /* Build check of the specialised kernel's source without a GPU: a synthetic cascade of n_stages depth-`depth` trees
  * through the generator and hiprtc for `arch` (e.g. "gfx950"); *code_bytes = size of the code object. */
 int wb_jit_compile_check(int depth, int n_stages, const char *arch, int64_t *code_bytes);
+/* The same for a tile of elem_bytes-wide elements (1: uint8 channels / WB_DTYPE_RANK8, 2: WB_DTYPE_RANK16). */
+int wb_jit_compile_check2(int depth, int n_stages, int elem_bytes, const char *arch, int64_t *code_bytes);
 
 /* Dense sliding-window cascade over all levels of all images.
  *   chn           [u][v][C] per level as written by wb_channels_launch (or caller-provided), of

@@ -10,6 +10,7 @@ import pytest
 
 import waldboost_amd as wb
 from waldboost_amd import engine as _engine
+from waldboost_amd import _native as nat
 from waldboost_amd.channels import channel_spec, read_opts
 from waldboost_amd.synth import random_tree_arrays, synth_image
 from util import oracle_detect
@@ -48,7 +49,8 @@ def check_ranks(M, img):
     """Every pixel of every level: rank bytes == number of the channel's thresholds below the float32 value.
     Returns the number of non-finite channel values met."""
     dm = M.device_cascade()
-    assert dm.rank_ok
+    assert dm.rank_dtype is not None
+    nan_rank = 65535 if dm.rank_dtype == nat.WB_DTYPE_RANK16 else 255
     shrink, n_per_oct, smooth, spec = read_opts(M.channel_opts)
     eng = _engine.get_engine(img.shape[0], img.shape[1], img.dtype, shrink, n_per_oct, smooth, 1, channels=spec)
     eng.load_images(img)
@@ -59,7 +61,7 @@ def check_ranks(M, img):
         chn, rank = eng.read_level(0, l), eng.read_rank_level(0, l)
         for c in range(4):
             want = np.searchsorted(S[c], chn[..., c], side="left").astype(np.int64)
-            want[np.isnan(chn[..., c])] = 255
+            want[np.isnan(chn[..., c])] = nan_rank
             assert np.array_equal(rank[..., c].astype(np.int64), want), (l, c)
         n_nan += int((~np.isfinite(chn)).sum())
     return n_nan
@@ -138,10 +140,93 @@ def test_clustered_thresholds_share_lookup_cells(spread):
     check_detect(M, img)
 
 
-def test_more_than_255_thresholds_per_channel_use_the_float_channels():
+def test_more_than_254_thresholds_per_channel_are_ranked_in_two_bytes():
+    """A long soft cascade (reference __init__.py:230-269 appends stages without bound): more distinct thresholds per channel
+    than a byte ranks -> WB_DTYPE_RANK16; value by value against np.searchsorted, detections against the oracle."""
     rng = np.random.default_rng(4)
     M = model_with_thresholds(rng, 400, 2, lambda n: rng.uniform(0, 60, n), theta_step=-0.05)
-    assert min(s.size for s in sorted_thresholds(M)) > 255 and not M.device_cascade().rank_ok
+    dm = M.device_cascade()
+    assert min(s.size for s in sorted_thresholds(M)) > 255 and not dm.rank_ok and dm.rank16_ok
+    assert dm.rank_dtype == nat.WB_DTYPE_RANK16
+    img = synth_image(130, 170, 15)
+    check_ranks(M, img)
+    check_detect(M, img)
+    # thresholds on the channel values themselves, special values, clusters: the 16-bit tables' grid is coarser (several
+    # thresholds per cell is the rule there)
+    img2 = synth_image(200, 280, 11)
+    special = np.array([np.nan, np.inf, -np.inf, -0.0, 0.0, 1e-30, 3.0e38], np.float32)
+
+    def draw(n):
+        v = channel_values(img2, n, rng)
+        return np.where(rng.random(n) < 0.05, rng.choice(special, n), v)
+    M2 = model_with_thresholds(rng, 360, 2, draw, theta_step=-0.05)
+    assert M2.device_cascade().rank_dtype == nat.WB_DTYPE_RANK16
+    check_ranks(M2, img2)
+    assert check_detect(M2, img2) >= 0
+    imf = (synth_image(120, 170, 13).astype(np.float32) * np.float32(0.25)).astype(np.float32)
+    imf[40:44, 60:64] = 3.0e38
+    with np.errstate(invalid="ignore", over="ignore"):
+        assert check_ranks(M2, imf) > 0
+    check_detect(M2, imf)
+
+
+def test_a_1024_stage_cascade_runs_on_16_bit_rank_tiles_with_its_specialised_kernel():
+    rng = np.random.default_rng(41)
+    M = model_with_thresholds(rng, 1024, 2, lambda n: rng.uniform(0, 60, n), theta_step=-0.02)
+    dm = M.device_cascade()
+    assert dm.rank_dtype == nat.WB_DTYPE_RANK16 and max(s.size for s in sorted_thresholds(M)) <= 1020
+    img = synth_image(150, 200, 17)
+    a = M.detect_raw(img)                                    # generic kernel on the 16-bit tile
+    assert dm.specialize() and nat.WB_DTYPE_RANK16 in dm.specialized()
+    b = M.detect_raw(img)                                    # the model-specialised kernel
+    for k in ("level", "r", "c", "alive"):
+        assert np.array_equal(a[k], b[k])
+    assert np.array_equal(bits(a["scores"]), bits(b["scores"]))
+    check_detect(M, img)
+
+
+def test_depth_3_trees_on_16_bit_rank_tiles():
+    rng = np.random.default_rng(42)
+    M = model_with_thresholds(rng, 128, 3, lambda n: rng.uniform(0, 60, n), theta_step=-0.1)
+    dm = M.device_cascade()
+    if dm.rank_ok:                                           # (896 thresholds spread over four channels may fit a byte)
+        dm.rank_dtype = nat.WB_DTYPE_RANK16
+    assert dm.rank16_ok
+    img = synth_image(170, 230, 18)
+    check_ranks(M, img)
+    a = M.detect_raw(img)
+    assert dm.specialize(nat.WB_DTYPE_RANK16) and nat.WB_DTYPE_RANK16 in dm.specialized()
+    b = M.detect_raw(img)
+    for k in ("level", "r", "c", "alive"):
+        assert np.array_equal(a[k], b[k])
+    assert np.array_equal(bits(a["scores"]), bits(b["scores"]))
+    check_detect(M, img)
+
+
+def test_the_same_cascade_in_one_and_in_two_byte_ranks():
+    """A model both forms apply to, forced through the 16-bit one: identical results (engine buffers re-allocated between
+    the forms, captured graphs dropped)."""
+    rng = np.random.default_rng(43)
+    M = model_with_thresholds(rng, 40, 2, lambda n: rng.uniform(0, 60, n))
+    img = synth_image(200, 264, 19)
+    dm = M.device_cascade()
+    assert dm.rank_dtype == nat.WB_DTYPE_RANK8 and dm.rank16_ok
+    a = [M.detect_raw(img) for _ in range(3)][-1]
+    dm.rank_dtype = nat.WB_DTYPE_RANK16
+    check_ranks(M, img)
+    b = [M.detect_raw(img) for _ in range(3)][-1]
+    dm.rank_dtype = nat.WB_DTYPE_RANK8
+    c = M.detect_raw(img)
+    for k in ("level", "r", "c", "alive"):
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k])
+    assert np.array_equal(bits(a["scores"]), bits(b["scores"])) and a["scores"].size > 0
+
+
+def test_more_than_1020_thresholds_per_channel_use_the_float_channels():
+    rng = np.random.default_rng(5)
+    M = model_with_thresholds(rng, 1500, 2, lambda n: rng.uniform(0, 60, n), theta_step=-0.01)
+    dm = M.device_cascade()
+    assert min(s.size for s in sorted_thresholds(M)) > 1020 and not dm.rank_ok and not dm.rank16_ok and dm.rank_dtype is None
     check_detect(M, synth_image(130, 170, 15))
 
 

@@ -41,6 +41,16 @@ def test_specialised_cascade_kernel_source_compiles_for_gfx950_without_a_gpu(dep
     assert n.value > 4096
 
 
+@pytest.mark.parametrize("depth,stages,eb", [(2, 128, 2), (3, 40, 2), (2, 1024, 1), (2, 1024, 2)])
+def test_specialised_kernel_source_compiles_for_16_bit_tiles_and_long_cascades(depth, stages, eb):
+    """The same generator for tiles of two-byte elements (WB_DTYPE_RANK16) and for cascades whose stage table is not
+    mirrored in LDS (1024 stages: only the first segments are unrolled, the rest runs the kernel's generic loop)."""
+    lib = nat.load()
+    n = C.c_int64()
+    nat.check(lib.wb_jit_compile_check2(depth, stages, eb, b"gfx950", C.byref(n)), "wb_jit_compile_check2")
+    assert n.value > 4096
+
+
 def test_abi_struct_sizes_match_header():
     assert nat.LEVEL_DTYPE.itemsize == 64 and nat.TILE_DTYPE.itemsize == 8 and nat.DET_DTYPE.itemsize == 16
     header = open(os.path.join(ROOT, "include", "waldboost_hip.h")).read()

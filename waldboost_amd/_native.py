@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WB_NATIVE_LIB") or os.path.join(_HERE, "csrc", "libwaldboost_hip.so")
 
 WB_DTYPE_U8, WB_DTYPE_F32, WB_DTYPE_RANK8 = 0, 1, 2
+WB_DTYPE_RANK16 = 13
 WB_DTYPE_F64, WB_DTYPE_I8, WB_DTYPE_I16, WB_DTYPE_U16, WB_DTYPE_I32, WB_DTYPE_U32 = 3, 4, 5, 6, 7, 8
 WB_ERR_INVALID, WB_ERR_HIP, WB_ERR_UNSUPPORTED = -1, -2, -3
 WB_DET_SHARDS = 64
@@ -37,7 +38,7 @@ assert PATCH_DTYPE.itemsize == 16
 class WbModelInfo(C.Structure):
     _fields_ = [("n_stages", C.c_int32), ("depth", C.c_int32), ("m", C.c_int32), ("n", C.c_int32),
                 ("C", C.c_int32), ("tile_rows", C.c_int32), ("tile_cols", C.c_int32), ("lds_bytes", C.c_int32),
-                ("rank_ok", C.c_int32), ("specialized", C.c_int32)]
+                ("rank_ok", C.c_int32), ("specialized", C.c_int32), ("rank16_ok", C.c_int32)]
 
 
 # every symbol include/waldboost_hip.h declares: name -> (restype, argtypes)
@@ -56,7 +57,7 @@ SYMBOLS = {
                                      _P, _P, C.c_int64]),
     "wb_channels_launch_x": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int,
                                        _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P, C.c_int64,
-                                       _P, _P, C.c_int64, _P]),
+                                       _P, _P, C.c_int64, _P, C.c_int]),
     "wb_channels_tile_patches": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P]),
     "wb_resize_level_launch": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, _P]),
     "wb_pool_smooth_launch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
@@ -67,6 +68,7 @@ SYMBOLS = {
     "wb_model_info": (C.c_int, [_P, C.POINTER(WbModelInfo)]),
     "wb_model_specialize": (C.c_int, [_P, C.c_int]),
     "wb_jit_compile_check": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int64)]),
+    "wb_jit_compile_check2": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int64)]),
     "wb_rankgroup_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(_P)]),
     "wb_rankgroup_model": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "wb_rankgroup_destroy": (C.c_int, [_P]),

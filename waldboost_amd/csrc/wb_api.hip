@@ -11,8 +11,8 @@
 
 int wb_cascade_prepare(int depth, int rpw, int waves);  // wb_cascade.hip
 int wb_cascade_group(int depth);                        // stages evaluated per group
-int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch,
-               void **func_out);   // wb_jit.hip
+int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch, int eb,
+               int lds_stages, void **func_out);   // wb_jit.hip
 
 static thread_local char g_err[512] = "";
 
@@ -59,6 +59,7 @@ int tree_depth(const TreeView &t, int node) {
 // integers (stored in the float slots): for an integer pixel v, `v <= thr` is `v <= floor(thr)`; a NaN or negative
 // threshold is never met (-1), anything from 255 up always (255).
 // BYTES == 2: the byte tile holds threshold ranks of float32 pixels (WbModel::bin_*): the integer is the node's rank.
+// BYTES == 3: the same with 16-bit ranks (WbModel::bin16_*): byte offsets into a tile of two-byte elements.
 template <int BYTES>
 void fill(const TreeView &t, int node, int ci, int d, int D, int rows, int pitch, int C, int32_t *off, float *thr,
           float *pred) {
@@ -76,10 +77,10 @@ void fill(const TreeView &t, int node, int ci, int d, int D, int rows, int pitch
     }
     int fr = t.feature[node * 3 + 0], fc = t.feature[node * 3 + 1], ch = t.feature[node * 3 + 2];
     if (BYTES) {
-        off[ci] = (fr * pitch + fc) * C + ch;
+        off[ci] = ((fr * pitch + fc) * C + ch) * (BYTES == 3 ? 2 : 1);       // (BYTES == 3: the tile's elements are 16-bit ranks)
         const float th = t.threshold[node];
         int32_t ti = !(th >= 0.0f) ? -1 : (th >= 255.0f ? 255 : (int32_t)floorf(th));
-        if (BYTES == 2) ti = t.rank[node];
+        if (BYTES >= 2) ti = t.rank[node];
         memcpy(&thr[ci], &ti, 4);
     } else {
         off[ci] = ((ch * rows + fr) * pitch + fc) * 4;   // byte offset inside the LDS tile
@@ -96,11 +97,13 @@ struct RankTables {
     std::vector<float> S[4];
     float k[4], b[4];
     int K = 1;
-    std::vector<uint8_t> lut;      // float S[4][WB_BIN_SLOTS], then uint8 base[4][WB_BIN_CELLS]
+    std::vector<uint8_t> lut;      // float S[4][slots], then base[4][cells]: uint8 (narrow) or uint16 (wide)
 };
 
-bool build_rank_tables(const std::vector<const std::vector<TreeView> *> &sets, RankTables &rt) {
-    const int N = WB_BIN_CELLS;
+// wide: the 16-bit form (WB_BIN16_*: up to 1022 thresholds per channel, 512 cells, uint16 base counts)
+bool build_rank_tables(const std::vector<const std::vector<TreeView> *> &sets, RankTables &rt, bool wide = false) {
+    const int N = wide ? WB_BIN16_CELLS : WB_BIN_CELLS, SLOTS = wide ? WB_BIN16_SLOTS : WB_BIN_SLOTS;
+    const int MAXT = wide ? WB_BIN16_MAX : WB_BIN_MAX;
     for (const std::vector<TreeView> *trees : sets)
         for (const TreeView &t : *trees)
             for (int i = 0; i < t.k; ++i)
@@ -111,33 +114,59 @@ bool build_rank_tables(const std::vector<const std::vector<TreeView> *> &sets, R
     for (int c = 0; c < 4; ++c) {
         std::sort(rt.S[c].begin(), rt.S[c].end());
         rt.S[c].erase(std::unique(rt.S[c].begin(), rt.S[c].end()), rt.S[c].end());     // (== merges -0.0 and 0.0)
-        if ((int)rt.S[c].size() > WB_BIN_MAX) return false;
+        if ((int)rt.S[c].size() > MAXT) return false;
     }
-    rt.lut.assign((size_t)4 * WB_BIN_SLOTS * 4 + (size_t)4 * N, 0);
+    rt.lut.assign((size_t)4 * SLOTS * 4 + (size_t)4 * N * (wide ? 2 : 1), 0);
     float *Stab = reinterpret_cast<float *>(rt.lut.data());
-    uint8_t *base = rt.lut.data() + 4 * WB_BIN_SLOTS * 4;
+    uint8_t *base8 = rt.lut.data() + (size_t)4 * SLOTS * 4;
+    uint16_t *base16 = reinterpret_cast<uint16_t *>(base8);
     rt.K = 1;
+    const int KMAX = wide ? 64 : 16;
     for (int c = 0; c < 4; ++c) {
-        float lo = INFINITY, hi = -INFINITY;
+        // the grid spans [lo, hi] of the channel's finite thresholds -- or, when a few far-out thresholds (1e30 next to
+        // values around 10) would squeeze all the others into one cell, a trimmed range: whatever lies outside lands in
+        // the two end cells (cell() clamps; it stays non-decreasing in v for any k > 0, which is all the ranks need)
+        std::vector<float> fin;
         for (float v : rt.S[c])
-            if (isfinite(v)) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
-        double k = 1.0, b = 1.0;
-        if (hi > lo) k = (double)(N - 2) / ((double)hi - (double)lo);
-        if (lo <= hi) b = 1.0 - (double)lo * k;
-        rt.k[c] = (float)k;
-        rt.b[c] = (float)b;
-        if (!(isfinite(rt.k[c]) && isfinite(rt.b[c]) && rt.k[c] > 0.0f)) return false;
+            if (isfinite(v)) fin.push_back(v);
         std::vector<int> cnt((size_t)N, 0);
-        for (float v : rt.S[c]) cnt[bin_cell(v, rt.k[c], rt.b[c], N)]++;    // non-decreasing in v
+        const double trims[] = {0.0, 0.01, 0.03, 0.1, 0.25};
+        bool placed = false;
+        for (double q : trims) {
+            float lo = INFINITY, hi = -INFINITY;
+            if (!fin.empty()) {
+                const size_t n = fin.size(), cut = (size_t)(q * (double)n);
+                lo = fin[cut < n ? cut : n - 1];
+                hi = fin[n - 1 - (cut < n ? cut : n - 1)];
+                if (hi < lo) { const float t = lo; lo = hi; hi = t; }
+            }
+            double k = 1.0, b = 1.0;
+            if (hi > lo) k = (double)(N - 2) / ((double)hi - (double)lo);
+            if (lo <= hi) b = 1.0 - (double)lo * k;
+            rt.k[c] = (float)k;
+            rt.b[c] = (float)b;
+            if (!(isfinite(rt.k[c]) && isfinite(rt.b[c]) && rt.k[c] > 0.0f)) continue;
+            std::fill(cnt.begin(), cnt.end(), 0);
+            int worst = 0;
+            for (float v : rt.S[c]) {
+                const int at = ++cnt[bin_cell(v, rt.k[c], rt.b[c], N)];    // non-decreasing in v
+                worst = at > worst ? at : worst;
+            }
+            if (worst <= KMAX) { placed = true; break; }
+        }
+        if (!placed) return false;
         int run = 0;
         for (int j = 0; j < N; ++j) {
-            base[(size_t)c * N + j] = (uint8_t)run;
+            if (wide)
+                base16[(size_t)c * N + j] = (uint16_t)run;
+            else
+                base8[(size_t)c * N + j] = (uint8_t)run;
             run += cnt[j];
             if (cnt[j] > rt.K) rt.K = cnt[j];
         }
-        for (int j = 0; j < WB_BIN_SLOTS; ++j) Stab[c * WB_BIN_SLOTS + j] = j < (int)rt.S[c].size() ? rt.S[c][j] : INFINITY;
+        for (int j = 0; j < SLOTS; ++j) Stab[c * SLOTS + j] = j < (int)rt.S[c].size() ? rt.S[c][j] : INFINITY;
     }
-    return rt.K <= 16;
+    return rt.K <= KMAX;
 }
 
 // rank[node] = index of the node's threshold in its channel's table (-1: leaf or NaN threshold); sets TreeView::rank
@@ -155,13 +184,16 @@ void assign_ranks(std::vector<TreeView> &trees, const int32_t *node_off, const R
 
 // the stage records of a cascade for byte tiles of threshold ranks (fill<2>): (n_stages + G) records of SD dwords
 void pack_rank_stages(const std::vector<TreeView> &trees, const float *theta, int D, int rows, int pitch, int C, int SD, int G,
-                      std::vector<int32_t> &packed) {
+                      std::vector<int32_t> &packed, bool wide = false) {
     const int NI = (1 << D) - 1, NL = 1 << D, n_stages = (int)trees.size();
     packed.assign((size_t)(n_stages + G) * SD, 0);
     for (int s = n_stages; s < n_stages + G; ++s) reinterpret_cast<float *>(packed.data() + (size_t)s * SD)[2 * NI + NL] = -INFINITY;
     for (int s = 0; s < n_stages; ++s) {
         int32_t *rec = packed.data() + (size_t)s * SD;
-        fill<2>(trees[s], 0, 0, 0, D, rows, pitch, C, rec, reinterpret_cast<float *>(rec + NI), reinterpret_cast<float *>(rec + 2 * NI));
+        if (wide)
+            fill<3>(trees[s], 0, 0, 0, D, rows, pitch, C, rec, reinterpret_cast<float *>(rec + NI), reinterpret_cast<float *>(rec + 2 * NI));
+        else
+            fill<2>(trees[s], 0, 0, 0, D, rows, pitch, C, rec, reinterpret_cast<float *>(rec + NI), reinterpret_cast<float *>(rec + 2 * NI));
         reinterpret_cast<float *>(rec)[2 * NI + NL] = theta[s];
     }
 }
@@ -232,6 +264,8 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
                        M->lds_stages * WB_STAGE_DWORDS(D) * 4 + 256;
         M->lds_bytes_u8 = ((((C * M->lds_rows * M->lds_pitch + 15) & ~15) + M->tile_rows * WB_CASC_TC * 8 + n_stages * 4 + 15) & ~15) +
                           M->lds_stages * WB_STAGE_DWORDS(D) * 4 + 256;
+        M->lds_bytes_u16 = ((((C * M->lds_rows * M->lds_pitch * 2 + 15) & ~15) + M->tile_rows * WB_CASC_TC * 8 + n_stages * 4 + 15) & ~15) +
+                           M->lds_stages * WB_STAGE_DWORDS(D) * 4 + 256;
         if (M->lds_bytes <= budget || rpw <= 1) break;
     }
     if (!generic && M->lds_bytes > 160 * 1024) {
@@ -299,6 +333,25 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         }
     }
     const std::vector<uint8_t> &lut = rt.lut;
+    // ... and the 16-bit form (WB_DTYPE_RANK16): for cascades whose thresholds do not fit a byte's ranks -- built for every
+    // model that qualifies (a few KiB), used by the engine when the 8-bit tables are not there
+    std::vector<int32_t> rank16((size_t)(n_stages ? node_off[n_stages] : 0), -1);
+    RankTables rt16;
+    std::vector<int32_t> pack16;
+    {
+        std::vector<const std::vector<TreeView> *> all = {&trees};
+        if (C == 4 && n_stages > 0 && getenv("WB_NO_RANKS") == nullptr && build_rank_tables(all, rt16, true)) {
+            std::vector<TreeView> trees16 = trees;
+            assign_ranks(trees16, node_off, rt16, rank16);
+            pack_rank_stages(trees16, theta, D, M->lds_rows, M->lds_pitch, C, WB_STAGE_DWORDS(D), wb_cascade_group(D), pack16, true);
+            M->bin16_ok = 1;
+            M->bin16_iters = rt16.K;
+            for (int c = 0; c < 4; ++c) {
+                M->bin16_k[c] = rt16.k[c];
+                M->bin16_b[c] = rt16.b[c];
+            }
+        }
+    }
 
     // ---- pack and upload the stage records
     const int NI = (1 << D) - 1, NL = 1 << D, SD = M->stage_dwords;
@@ -363,6 +416,14 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         if (e == hipSuccess) e = hipMemcpy(M->stages_dev, packed.data(), packed.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc((void **)&M->stages_u8_dev, packs[1].size() * 4);
         if (e == hipSuccess) e = hipMemcpy(M->stages_u8_dev, packs[1].data(), packs[1].size() * 4, hipMemcpyHostToDevice);
+        if (M->bin16_ok) {
+            M->stages_bin16_host = static_cast<int32_t *>(malloc(pack16.size() * 4 + 4));
+            memcpy(M->stages_bin16_host, pack16.data(), pack16.size() * 4);
+            if (e == hipSuccess) e = hipMalloc((void **)&M->stages_bin16_dev, pack16.size() * 4);
+            if (e == hipSuccess) e = hipMemcpy(M->stages_bin16_dev, pack16.data(), pack16.size() * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void **)&M->bin16_lut_dev, rt16.lut.size());
+            if (e == hipSuccess) e = hipMemcpy(M->bin16_lut_dev, rt16.lut.data(), rt16.lut.size(), hipMemcpyHostToDevice);
+        }
         if (M->bin_ok) {
             if (e == hipSuccess) e = hipMalloc((void **)&M->stages_bin_dev, packs[2].size() * 4);
             if (e == hipSuccess) e = hipMemcpy(M->stages_bin_dev, packs[2].data(), packs[2].size() * 4, hipMemcpyHostToDevice);
@@ -396,6 +457,9 @@ extern "C" int wb_model_destroy(WbModel *model) {
     if (model->stages_u8_dev) (void)hipFree(model->stages_u8_dev);
     if (model->stages_bin_dev) (void)hipFree(model->stages_bin_dev);
     if (model->bin_lut_dev) (void)hipFree(model->bin_lut_dev);
+    if (model->stages_bin16_dev) (void)hipFree(model->stages_bin16_dev);
+    if (model->bin16_lut_dev) (void)hipFree(model->bin16_lut_dev);
+    free(model->stages_bin16_host);
     free(model->stages_u8_host);
     free(model->stages_bin_host);
     void *g[] = {model->g_node_off, model->g_feat, model->g_thr, model->g_left, model->g_right, model->g_pred, model->g_theta};
@@ -416,7 +480,8 @@ extern "C" int wb_model_info(const WbModel *model, WbModelInfo *info) {
     info->tile_cols = WB_CASC_TC;
     info->lds_bytes = model->lds_bytes;
     info->rank_ok = model->bin_ok;
-    info->specialized = (model->jit_u8 ? 1 : 0) | (model->jit_bin ? 2 : 0);
+    info->specialized = (model->jit_u8 ? 1 : 0) | (model->jit_bin ? 2 : 0) | (model->jit_bin16 ? 4 : 0);
+    info->rank16_ok = model->bin16_ok;
     return WB_OK;
 }
 
@@ -424,7 +489,7 @@ extern "C" int wb_model_info(const WbModel *model, WbModelInfo *info) {
 // seconds), then taken from the process / disk cache.  wb_cascade_launch uses it from then on for that channel dtype.
 extern "C" int wb_model_specialize(WbModel *model, int chn_dtype) {
     WB_REQUIRE(model, "wb_model_specialize: null model");
-    if (chn_dtype != WB_DTYPE_U8 && chn_dtype != WB_DTYPE_RANK8) {
+    if (chn_dtype != WB_DTYPE_U8 && chn_dtype != WB_DTYPE_RANK8 && chn_dtype != WB_DTYPE_RANK16) {
         wb_set_error("wb_model_specialize: channel dtype %d has no specialised kernel (uint8 channels and threshold ranks do)", chn_dtype);
         return WB_ERR_UNSUPPORTED;
     }
@@ -432,19 +497,16 @@ extern "C" int wb_model_specialize(WbModel *model, int chn_dtype) {
         wb_set_error("wb_model_specialize: this model runs on the generic node-walk kernel (depth %d, %d stages)", model->depth, model->n_stages);
         return WB_ERR_UNSUPPORTED;
     }
-    const bool ranks = chn_dtype == WB_DTYPE_RANK8;
-    if (ranks && !model->bin_ok) {
-        wb_set_error("wb_model_specialize: this model has no rank tables (wb_model_info: rank_ok)");
+    const bool ranks = chn_dtype == WB_DTYPE_RANK8, ranks16 = chn_dtype == WB_DTYPE_RANK16;
+    if ((ranks && !model->bin_ok) || (ranks16 && !model->bin16_ok)) {
+        wb_set_error("wb_model_specialize: this model has no rank tables of that width (wb_model_info: rank_ok / rank16_ok)");
         return WB_ERR_UNSUPPORTED;
     }
-    void **slot = ranks ? &model->jit_bin : &model->jit_u8;
+    void **slot = ranks16 ? &model->jit_bin16 : ranks ? &model->jit_bin : &model->jit_u8;
     if (*slot) return WB_OK;
-    if (!model->lds_stages) {
-        wb_set_error("wb_model_specialize: %d stages exceed the LDS mirror of the stage table the specialised kernel reads leaf values from", model->n_stages);
-        return WB_ERR_UNSUPPORTED;
-    }
-    return wb_jit_get(ranks ? model->stages_bin_host : model->stages_u8_host, model->stage_words, model->n_stages,
-                      model->depth, model->rpw, model->waves, model->C, model->lds_rows, model->lds_pitch, slot);
+    return wb_jit_get(ranks16 ? model->stages_bin16_host : ranks ? model->stages_bin_host : model->stages_u8_host, model->stage_words,
+                      model->n_stages, model->depth, model->rpw, model->waves, model->C, model->lds_rows, model->lds_pitch, ranks16 ? 2 : 1,
+                      model->lds_stages, slot);
 }
 
 
@@ -522,6 +584,8 @@ extern "C" int wb_rankgroup_create(const WbModel *const *models, int n, WbRankGr
         }
         v->bin_lut_dev = g->lut_dev;
         v->jit_bin = nullptr;                               // (a specialised kernel bakes the thresholds' indices: per view)
+        v->bin16_ok = 0;                                    // (the group ranks in one byte; the member's own 16-bit tables are not the union's)
+        v->jit_bin16 = nullptr;
         v->stages_bin_dev = nullptr;
         v->stages_bin_host = static_cast<int32_t *>(malloc(packed.size() * 4 + 4));
         memcpy(v->stages_bin_host, packed.data(), packed.size() * 4);

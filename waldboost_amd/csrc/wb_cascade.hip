@@ -39,9 +39,9 @@
 
 namespace {
 
-template <int D, int RPW, int WAVES, bool U8>
+template <int D, int RPW, int WAVES, int EB>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_sgpr(80))) void cascade_tile_kernel(CascArgs a, const int32_t *__restrict__ stages) {
-    cascade_tile_body<D, RPW, WAVES, U8, false>(a, stages);
+    cascade_tile_body<D, RPW, WAVES, EB, false>(a, stages);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -527,10 +527,12 @@ template <int D>
 int launch_depth(hipStream_t st, dim3 grid, const CascArgs &a, int rpw, int waves, size_t lds) {
 #define WB_X(R, W)                                                                                          \
     if (rpw == R && waves == W) {                                                                           \
-        if (a.chn_u8)                                                                                       \
-            hipLaunchKernelGGL((cascade_tile_kernel<D, R, W, true>), grid, dim3(W * 64), lds, st, a, a.stages);  \
+        if (a.chn_u8 == 2)                                                                                  \
+            hipLaunchKernelGGL((cascade_tile_kernel<D, R, W, 2>), grid, dim3(W * 64), lds, st, a, a.stages);     \
+        else if (a.chn_u8)                                                                                  \
+            hipLaunchKernelGGL((cascade_tile_kernel<D, R, W, 1>), grid, dim3(W * 64), lds, st, a, a.stages);     \
         else                                                                                                \
-            hipLaunchKernelGGL((cascade_tile_kernel<D, R, W, false>), grid, dim3(W * 64), lds, st, a, a.stages); \
+            hipLaunchKernelGGL((cascade_tile_kernel<D, R, W, 0>), grid, dim3(W * 64), lds, st, a, a.stages);     \
         WB_HIP_CHECK(hipGetLastError());                                                                    \
         return WB_OK;                                                                                       \
     }
@@ -544,9 +546,11 @@ template <int D>
 int prepare_depth(int rpw, int waves) {
 #define WB_X(R, W)                                                                                          \
     if (rpw == R && waves == W) {                                                                           \
-        WB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&cascade_tile_kernel<D, R, W, false>), \
+        WB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&cascade_tile_kernel<D, R, W, 0>),  \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));          \
-        WB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&cascade_tile_kernel<D, R, W, true>), \
+        WB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&cascade_tile_kernel<D, R, W, 1>),  \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));          \
+        WB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&cascade_tile_kernel<D, R, W, 2>),  \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));          \
         return WB_OK;                                                                                       \
     }
@@ -587,20 +591,21 @@ extern "C" int wb_cascade_launch_z(void *stream, const WbModel *model, const voi
     WB_REQUIRE(det || shard_capacity == 0, "wb_cascade_launch: det is null but capacity > 0");
     WB_REQUIRE(batch >= 1 && batch <= 65535, "wb_cascade_launch: batch %d out of range", batch);
     WB_REQUIRE(n_levels >= 1 && n_tiles >= 1, "wb_cascade_launch: empty launch");
-    WB_REQUIRE(chn_dtype == WB_DTYPE_F32 || chn_dtype == WB_DTYPE_U8 || chn_dtype == WB_DTYPE_RANK8,
+    WB_REQUIRE(chn_dtype == WB_DTYPE_F32 || chn_dtype == WB_DTYPE_U8 || chn_dtype == WB_DTYPE_RANK8 || chn_dtype == WB_DTYPE_RANK16,
                "wb_cascade_launch: channel dtype %d (float32, uint8 or ranks)", chn_dtype);
     CascArgs a;
     a.chn = chn;
-    a.chn_u8 = chn_dtype != WB_DTYPE_F32;
+    a.chn_u8 = chn_dtype == WB_DTYPE_F32 ? 0 : (chn_dtype == WB_DTYPE_RANK16 ? 2 : 1);      // element bytes of a byte tile
     a.chn_stride = chn_stride;
     a.levels = levels;
     a.tiles = tiles;
     a.n_levels = n_levels;
     // WB_DTYPE_RANK8: the bytes are threshold ranks of this model (wb_channels_launch wrote them): the uint8 tile
     // kernel with the rank records
-    const bool ranks = chn_dtype == WB_DTYPE_RANK8;
+    const bool ranks = chn_dtype == WB_DTYPE_RANK8, ranks16 = chn_dtype == WB_DTYPE_RANK16;
     WB_REQUIRE(!ranks || (model->bin_ok && !model->generic), "wb_cascade_launch: this model has no rank tables (wb_model_info: rank_ok)");
-    a.stages = ranks ? model->stages_bin_dev : (a.chn_u8 ? model->stages_u8_dev : model->stages_dev);
+    WB_REQUIRE(!ranks16 || (model->bin16_ok && !model->generic), "wb_cascade_launch: this model has no 16-bit rank tables (wb_model_info: rank16_ok)");
+    a.stages = ranks16 ? model->stages_bin16_dev : ranks ? model->stages_bin_dev : (a.chn_u8 ? model->stages_u8_dev : model->stages_dev);
     a.T = model->n_stages;
     a.m = model->m;
     a.n = model->n;
@@ -648,11 +653,11 @@ extern "C" int wb_cascade_launch_z(void *stream, const WbModel *model, const voi
         WB_HIP_CHECK(hipGetLastError());
         return WB_OK;
     }
-    const size_t lds = (size_t)(a.chn_u8 ? model->lds_bytes_u8 : model->lds_bytes);
+    const size_t lds = (size_t)(ranks16 ? model->lds_bytes_u16 : a.chn_u8 ? model->lds_bytes_u8 : model->lds_bytes);
     // the model-specialised kernel, when wb_model_specialize has built one for this kind of byte tile (WB_CASC_JIT=0:
     // diagnostic, stay on the generic kernel)
     static const bool jit_off = getenv("WB_CASC_JIT") && atoi(getenv("WB_CASC_JIT")) == 0;
-    if (void *jf = a.chn_u8 && !jit_off ? (ranks ? model->jit_bin : model->jit_u8) : nullptr) {
+    if (void *jf = a.chn_u8 && !jit_off ? (ranks16 ? model->jit_bin16 : ranks ? model->jit_bin : model->jit_u8) : nullptr) {
         const int32_t *stages = a.stages;
         void *params[] = {&a, &stages};
         WB_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)jf, grid.x, grid.y, 1, (unsigned)model->waves * 64, 1, 1, (unsigned)lds, st,

@@ -45,11 +45,15 @@ namespace {
 // the stage table of a BAKED build (wb_jit.hip generates the two macros); a one-word stand-in otherwise
 #ifdef WB_JIT_BAKED
 static __device__ const int32_t kWbStages[] = {WB_JIT_STAGE_WORDS};
+#ifndef WB_JIT_LDS_STAGES
+#define WB_JIT_LDS_STAGES WB_JIT_T      // stage records mirrored in LDS: all of them, or 0 (a table beyond 16 KiB: long cascades)
+#endif
 #else
 static __device__ const int32_t kWbStages[1] = {0};
 #define WB_JIT_SEGMENTS(X)
 // (a BAKED build also knows the model's geometry at compile time: stage count, channels, LDS tile rows and pitch)
 #define WB_JIT_T 0
+#define WB_JIT_LDS_STAGES 0
 #define WB_JIT_C 0
 #define WB_JIT_ROWS 0
 #define WB_JIT_PITCH 0
@@ -57,11 +61,12 @@ static __device__ const int32_t kWbStages[1] = {0};
 // Dynamic LDS layout of the tile kernel (ALL of its LDS: no static __shared__, so the region starts at LDS address 0
 // and a BAKED build can use absolute LDS addresses as instruction offsets):
 //   [ channel tile | per-wave queues TR*64*8 | hist T*4 | (16-aligned) stage-table mirror | control words 128 B ]
-__host__ __device__ constexpr size_t wb_lds_tile_bytes(bool u8, int C, int rows, int pitch) {
-    return u8 ? (((size_t)C * rows * pitch + 15) & ~(size_t)15) : (size_t)C * rows * pitch * 4;
+// eb: bytes per element of a byte tile (1: uint8 channels / 8-bit ranks, 2: 16-bit ranks), 0: the planar float32 tile
+__host__ __device__ constexpr size_t wb_lds_tile_bytes(int eb, int C, int rows, int pitch) {
+    return eb ? (((size_t)C * rows * pitch * eb + 15) & ~(size_t)15) : (size_t)C * rows * pitch * 4;
 }
-__host__ __device__ constexpr size_t wb_lds_stab_off(bool u8, int C, int rows, int pitch, int TR, int T) {
-    return (wb_lds_tile_bytes(u8, C, rows, pitch) + (size_t)TR * 64 * 8 + (size_t)T * 4 + 15) & ~(size_t)15;
+__host__ __device__ constexpr size_t wb_lds_stab_off(int eb, int C, int rows, int pitch, int TR, int T) {
+    return (wb_lds_tile_bytes(eb, C, rows, pitch) + (size_t)TR * 64 * 8 + (size_t)T * 4 + 15) & ~(size_t)15;
 }
 #define WB_LDS_CTL_BYTES 256
 // experiment switches (A/B builds; the defaults are what measured best)
@@ -169,8 +174,11 @@ template <int D> struct Stage {
     // LDS tile (offsets in the records are bytes too: one v_add per gather)
     // BYTES: the tile holds uint8 pixels ([row][col][C] bytes), the record's offsets address it and its
     // thresholds are integers (wb_api.hip: fill<true>): an 8-bit gather and an integer compare per node.
-    template <bool BYTES> static __device__ inline bool goes_right(const char *t8, int at, float th) {
-        if constexpr (BYTES) {
+    template <int BYTES> static __device__ inline bool goes_right(const char *t8, int at, float th) {
+        if constexpr (BYTES == 2) {                      // 16-bit ranks: offsets are bytes, always even
+            const int v = *reinterpret_cast<const uint16_t *>(t8 + at);
+            return !(v <= __float_as_int(th));
+        } else if constexpr (BYTES == 1) {
             const int v = *reinterpret_cast<const uint8_t *>(t8 + at);
             return !(v <= __float_as_int(th));
         } else {
@@ -181,7 +189,7 @@ template <int D> struct Stage {
     // the same walk with EVERY node's feature gathered up front (depth <= 2): one LDS round trip instead of one per level,
     // no selects of offsets or thresholds -- for records that sit in vector registers (the stage-parallel tail: one stage
     // per lane), where the selects of the leaf values cost no moves
-    template <bool BYTES = false> __device__ inline float eval_all(const float *tile, int base) const {
+    template <int BYTES = 0> __device__ inline float eval_all(const float *tile, int base) const {
         if constexpr (D > 2) {
             return eval<BYTES>(tile, base);
         } else {
@@ -196,7 +204,7 @@ template <int D> struct Stage {
             }
         }
     }
-    template <bool BYTES = false> __device__ inline float eval(const float *tile, int base) const {
+    template <int BYTES = 0> __device__ inline float eval(const float *tile, int base) const {
         const char *t8 = reinterpret_cast<const char *>(tile);
         bool right[D];
 #pragma unroll
@@ -230,10 +238,15 @@ __device__ inline int lane_rank(unsigned long long mask) {
 //     ~13 with the records in scalar registers.
 //   * otherwise: the generic walk on the constant record (selects with literal operands).
 typedef const __attribute__((address_space(3))) unsigned char *WbLdsU8;
+typedef const __attribute__((address_space(3))) unsigned short *WbLdsU16;
 typedef const __attribute__((address_space(3))) float *WbLdsF32;
-template <int D, bool U8, int TR, int T> struct StageAt {
+template <int D, int EB, int TR, int T> struct StageAt {
     static constexpr int SD = WB_STAGE_DWORDS(D), NI = WB_STAGE_NI(D), NL = WB_STAGE_NL(D);
-    static constexpr bool FAST = U8 && D <= 2;
+    static constexpr bool FAST = EB != 0 && D <= 2 && WB_JIT_LDS_STAGES != 0;     // (the leaf values come from the LDS mirror)
+    // (16-bit elements: the same bit trick one byte wider -- `x > thr` is bit 16 of x + (65535 - thr), the right child's
+    // sum carries bit 17, and 4 * leaf = (y >> 14) & 12)
+    static constexpr uint32_t XMAX = EB == 2 ? 65535u : 255u, RIGHT = EB == 2 ? 131072u : 512u;
+    static constexpr int LEAF_SHIFT = EB == 2 ? 14 : 6;
     static __device__ __forceinline__ int off(int i) { return kWbStages[T * SD + i]; }
     static __device__ __forceinline__ int thr(int i) { return kWbStages[T * SD + NI + i]; }
     static __device__ __forceinline__ float theta() { return as_f(kWbStages[T * SD + 2 * NI + NL]); }
@@ -242,23 +255,28 @@ template <int D, bool U8, int TR, int T> struct StageAt {
         if constexpr (FAST) {
             // absolute LDS addresses (the tile starts at 0, the stage mirror at a compile-time offset): every constant
             // part of an address is an instruction offset, nothing is added on the vector unit
-            constexpr uint32_t PRED = (uint32_t)wb_lds_stab_off(true, WB_JIT_C, WB_JIT_ROWS, WB_JIT_PITCH, TR, WB_JIT_T) + (T * SD + 2 * NI) * 4;
-            auto px = [&](int i) { return (uint32_t)*(WbLdsU8)(uint32_t)(base + off(i)); };
+            constexpr uint32_t PRED = (uint32_t)wb_lds_stab_off(EB, WB_JIT_C, WB_JIT_ROWS, WB_JIT_PITCH, TR, WB_JIT_T) + (T * SD + 2 * NI) * 4;
+            auto px = [&](int i) {
+                if constexpr (EB == 2)
+                    return (uint32_t)*(WbLdsU16)(uint32_t)(base + off(i));
+                else
+                    return (uint32_t)*(WbLdsU8)(uint32_t)(base + off(i));
+            };
             uint32_t y;
             if constexpr (D == 1) {
-                y = px(0) + (uint32_t)(255 - thr(0));
-                y = (y >> 6) & 4u;
+                y = px(0) + (uint32_t)((int)XMAX - thr(0));
+                y = (y >> LEAF_SHIFT) & 4u;
             } else {
                 const uint32_t x0 = px(0), xl = px(1), xr = px(2);
-                const uint32_t yl = xl + (uint32_t)(255 - thr(1)), yr = xr + (uint32_t)(767 - thr(2));
+                const uint32_t yl = xl + (uint32_t)((int)XMAX - thr(1)), yr = xr + (uint32_t)((int)(XMAX + RIGHT) - thr(2));
                 y = ((int)x0 > thr(0)) ? yr : yl;
-                y = (y >> 6) & 12u;
+                y = (y >> LEAF_SHIFT) & 12u;
             }
             return *(WbLdsF32)(PRED + y);
         } else {
             Stage<D> st;
             st.load(kWbStages + T * SD);
-            return st.template eval<U8>(tile, base);
+            return st.template eval<EB>(tile, base);
         }
     }
 };
@@ -287,7 +305,7 @@ template <int B, int E, int S, class F> __device__ __forceinline__ void wb_stati
     }
 }
 
-template <int D, int RPW, int WAVES, bool U8, bool BAKED>
+template <int D, int RPW, int WAVES, int EB, bool BAKED>
 __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32_t *__restrict__ stages) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert((2 * WAVES + 1) * 4 <= WB_LDS_CTL_BYTES, "control words");
@@ -311,8 +329,9 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
 
     float *tile = reinterpret_cast<float *>(smem);
     // float32 channels: planar float tile [C][rows][pitch]; uint8 channels: the pixels as they are, [rows][pitch][C] bytes
-    const size_t tile_bytes = wb_lds_tile_bytes(U8, nC, rows, pitch);
-    const int px_stride = U8 ? nC : 4;                      // bytes between horizontally adjacent windows' origins
+    constexpr bool U8 = EB != 0;                            // a byte tile (8- or 16-bit elements)
+    const size_t tile_bytes = wb_lds_tile_bytes(EB, nC, rows, pitch);
+    const int px_stride = EB ? nC * EB : 4;                 // bytes between horizontally adjacent windows' origins
     uint2 *queue = reinterpret_cast<uint2 *>(smem + tile_bytes) + wave * (RPW * 64);
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem + tile_bytes + (size_t)TR * 64 * 8);
 
@@ -321,10 +340,10 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     const int r0 = tile_d.ty * TR, c0 = tile_d.tx * WB_CASC_TC;
 
     // LDS mirror of the stage table (when it is small enough): the tail reads one record per lane
-    const size_t stab_off = wb_lds_stab_off(U8, nC, rows, pitch, TR, T);
+    const size_t stab_off = wb_lds_stab_off(EB, nC, rows, pitch, TR, T);
     int4 *stab = reinterpret_cast<int4 *>(smem + stab_off);
     // control words behind the mirror: the per-wave counts exchanged at stage 8 and (their own words) at stage 16
-    uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + stab_off + (size_t)(BAKED ? WB_JIT_T : a.lds_stages) * SD * 4);
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + stab_off + (size_t)(BAKED ? WB_JIT_LDS_STAGES : a.lds_stages) * SD * 4);
     uint32_t *wcnt2 = wcnt + WAVES;
     uint32_t *ticket = wcnt2 + WAVES;           // next unclaimed entry of the workgroup's survivor list (the stage-parallel tail)
     if (tid == 0) *ticket = 0u;                 // (visible behind the tile load's barrier)
@@ -340,7 +359,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     for (int t = tid; t < T; t += NT) hist[t] = 0;
     // the stage mirror: its first NT vectors are REQUESTED here and stored behind the tile (as a loop of its own in front
     // of the tile loads it put one more memory round trip on every workgroup's way to the first barrier)
-    const int n_stab = (BAKED ? WB_JIT_T : a.lds_stages) * (SD / 4);
+    const int n_stab = (BAKED ? WB_JIT_LDS_STAGES : a.lds_stages) * (SD / 4);
     int4 stab_mine = make_int4(0, 0, 0, 0);
     if (tid < n_stab) stab_mine = reinterpret_cast<const int4 *>(stages)[tid];
 
@@ -348,6 +367,47 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     const float *chn = reinterpret_cast<const float *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
     const uint8_t *chn8 = reinterpret_cast<const uint8_t *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
     if (a.dbg & 1) {
+    } else if (EB == 2 && a.C == 4 && (pitch & 1) == 0) {
+        // 16-bit ranks, 8 bytes per pixel: 16 bytes = TWO pixels per lane, one 16-byte LDS write (as below, a group may read
+        // one pixel past the end of a level row: the buffers carry 16 spare elements)
+        constexpr int U = 2;
+        const int ngrp = (WB_CASC_TC + a.n - 1 + 1) >> 1;            // 2-pixel groups per tile row (<= pitch / 2)
+        const int total = rows * ngrp;
+        const uint32_t m_ngrp = 0xFFFFFFFFu / (uint32_t)ngrp + 1u;
+        struct __attribute__((aligned(8))) Px2 { uint32_t x, y, z, w; };      // two pixels, 8-byte aligned only
+        const uint16_t *chn16 = reinterpret_cast<const uint16_t *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
+        uint32_t *tile32 = reinterpret_cast<uint32_t *>(smem);
+        for (int e0 = tid; e0 < total; e0 += NT * U) {
+            Px2 v[U];
+            int dst[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                uint32_t e = (uint32_t)(e0 + k * NT);
+                e = e < (uint32_t)total ? e : (uint32_t)total - 1u;  // duplicates rewrite the same values
+                const uint32_t row = __umulhi(e, m_ngrp), grp = e - row * (uint32_t)ngrp;
+                int gr = r0 + (int)row, gc = c0 + 2 * (int)grp;
+                gr = gr < L.u ? gr : L.u - 1;
+                gc = gc < L.v ? gc : L.v - 1;
+                v[k] = *reinterpret_cast<const Px2 *>(chn16 + ((int64_t)gr * L.v + gc) * 4);
+                dst[k] = (int)(2u * (row * (uint32_t)pitch + 2u * grp));       // dwords: two per pixel
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) *reinterpret_cast<uint4 *>(tile32 + dst[k]) = make_uint4(v[k].x, v[k].y, v[k].z, v[k].w);
+        }
+    } else if (EB == 2) {
+        // 16-bit elements of any channel count: the tile [rows][pitch][C], element by element
+        uint16_t *tile16 = reinterpret_cast<uint16_t *>(smem);
+        const uint16_t *chn16 = reinterpret_cast<const uint16_t *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
+        const int total = a.C * rows * pitch;
+        for (int idx = tid; idx < total; idx += NT) {
+            const int ch = idx % a.C;
+            const int rc = idx / a.C;
+            const int col = rc % pitch, row = rc / pitch;
+            const int gr = r0 + row, gc = c0 + col;
+            uint16_t v = 0;
+            if (gr < L.u && gc < L.v) v = chn16[((int64_t)gr * L.v + gc) * a.C + ch];
+            tile16[idx] = v;
+        }
     } else if (U8 && a.C == 4 && (pitch & 3) == 0) {
         // uint8 channels, one dword per pixel, kept as they are: the tile is [rows][pitch] dwords, a quarter of
         // the float tile (twice the workgroups per CU), loaded 16 bytes = FOUR pixels per lane, stored with one
@@ -473,7 +533,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
                 wb_static_for<0, G, 1>([&](auto gg) {
                     constexpr int g = decltype(gg)::value;
 #pragma unroll
-                    for (int j = 0; j < RPW; ++j) p[g][j] = StageAt<D, U8, TR, t + g>::eval(tile, base[j]);
+                    for (int j = 0; j < RPW; ++j) p[g][j] = StageAt<D, EB, TR, t + g>::eval(tile, base[j]);
                     return true;
                 });
                 bool more = true;
@@ -484,7 +544,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
 #pragma unroll
                     for (int j = 0; j < RPW; ++j) cnt += __popcll(lm[j]);
                     asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(entered) : "s"(cnt), "n"(t + g));
-                    const float theta = StageAt<D, U8, TR, t + g>::theta();
+                    const float theta = StageAt<D, EB, TR, t + g>::theta();
                     const unsigned long long never = never_rejects<true>(theta) ? ~0ull : 0ull;
 #pragma unroll
                     for (int j = 0; j < RPW; ++j) {
@@ -508,7 +568,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int j = 0; j < RPW; ++j) p[g][j] = st[g].template eval<U8>(tile, base[j]);
+                for (int j = 0; j < RPW; ++j) p[g][j] = st[g].template eval<EB>(tile, base[j]);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (!FULL && t + g >= tA) break;
@@ -638,7 +698,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
                         float pc[G];
                         wb_static_for<0, G, 1>([&](auto gg) {
                             constexpr int g = decltype(gg)::value;
-                            pc[g] = StageAt<D, U8, TR, TB + g>::eval(tile, wbase);
+                            pc[g] = StageAt<D, EB, TR, TB + g>::eval(tile, wbase);
                             return true;
                         });
                         wb_static_for<TB, TE, G>([&](auto tt) {
@@ -647,7 +707,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
                             wb_static_for<0, G, 1>([&](auto gg) {
                                 constexpr int g = decltype(gg)::value;
                                 if constexpr (WB_SEG_PREFETCH && t + G < TE)
-                                    pn[g] = StageAt<D, U8, TR, t + G + g>::eval(tile, wbase);
+                                    pn[g] = StageAt<D, EB, TR, t + G + g>::eval(tile, wbase);
                                 else
                                     pn[g] = 0.0f;
                                 return true;
@@ -657,7 +717,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
                                 if constexpr (t + g < TE) {
                                     const int cnt = __popcll(am);
                                     asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(ent_c) : "s"(cnt), "n"(t + g - TB));
-                                    const float theta = StageAt<D, U8, TR, t + g>::theta();
+                                    const float theta = StageAt<D, EB, TR, t + g>::theta();
                                     h = h + pc[g];
                                     am &= __ballot(h >= theta) | (never_rejects<true>(theta) ? ~0ull : 0ull);
                                 }
@@ -669,7 +729,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
                                 if constexpr (WB_SEG_PREFETCH)
                                     pc[g] = pn[g];
                                 else if constexpr (t + G < TE)
-                                    pc[g] = StageAt<D, U8, TR, t + G + g>::eval(tile, wbase);
+                                    pc[g] = StageAt<D, EB, TR, t + G + g>::eval(tile, wbase);
                                 return true;
                             });
                             return true;
@@ -683,7 +743,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
                             for (int g = 0; g < G; ++g) st[g].load(sp + g * SD);
                             float p[G];
 #pragma unroll
-                            for (int g = 0; g < G; ++g) p[g] = st[g].template eval<U8>(tile, wbase);
+                            for (int g = 0; g < G; ++g) p[g] = st[g].template eval<EB>(tile, wbase);
 #pragma unroll
                             for (int g = 0; g < G; ++g) {
                                 if (t + g >= t_end) break;
@@ -771,7 +831,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
         const int t = rs + lane;
         const int tt = t < T ? t : T - 1;
         int32_t rec[SD];
-        if (BAKED || a.lds_stages) {
+        if (BAKED ? WB_JIT_LDS_STAGES != 0 : a.lds_stages != 0) {
 #pragma unroll
             for (int q = 0; q < SD / 4; ++q) {
                 int4 v = stab[tt * (SD / 4) + q];
@@ -797,7 +857,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             const int wbase = ((pos[w] >> 6) * pitch + (pos[w] & 63)) * px_stride;
-            const float p = WB_TAIL_ALL ? st.template eval_all<U8>(tile, wbase) : st.template eval<U8>(tile, wbase);
+            const float p = WB_TAIL_ALL ? st.template eval_all<EB>(tile, wbase) : st.template eval<EB>(tile, wbase);
             // Replay in stage order: lane k accumulates p_0 .. p_k one after the other -- the same
             // additions in the same order as the reference's running `hs +=` -- so it ends up
             // with the score the rejection test of stage rs+k sees.

@@ -44,6 +44,7 @@ struct ChanArgs {
     const uint4 *rank_lut;   // WbModel::bin_lut_dev: float S[4][256], then uint8 base[4][WB_BIN_CELLS]
     int rank_iters;
     float rank_k[4], rank_b[4];
+    int rank_wide;       // 0: WB_DTYPE_RANK8 (one dword per pixel), 1: WB_DTYPE_RANK16 (uint16 x 4 = 8 bytes per pixel; WB_BIN16_* tables)
 };
 
 // Diagnostic build only (make STAMPS=1): thread 0 of every workgroup stores s_memrealtime at the
@@ -780,7 +781,9 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ?
     using G = TileGeom<S, TU, TV, SMOOTH, NT>;
     constexpr int HS = G::HS, SV = G::SV, RH = G::RH, RW = G::RW, P = G::P;
     constexpr int PATCH_BYTES = sizeof(T) == 1 ? G::PATCH_BYTES : 0;
-    constexpr int UNI_BYTES = G::SH_BYTES > PATCH_BYTES ? G::SH_BYTES : PATCH_BYTES;
+    constexpr int UNI_MIN = G::SH_BYTES > PATCH_BYTES ? G::SH_BYTES : PATCH_BYTES;
+    constexpr int UNI_LUT = (S == 4 && sizeof(T) == 1 && WB_CHAN_S4_BYTES) ? ((G::SH_BYTES + 15) & ~15) + WB_BIN16_LUT_BYTES : 0;
+    constexpr int UNI_BYTES = UNI_MIN > UNI_LUT ? UNI_MIN : UNI_LUT;
     // Shrink 4, uint8 images (round 4): R holds the resized pixels as BYTES (they are integers 0..255) -- 5.9 KB instead of
     // 23 KB, and the rank tables are parked behind the shrunk tile in `uni` (the dead source patch) instead of in R: 31 KB of
     // LDS per workgroup = five per CU instead of three.  The kernel at this shrink is latency-bound (16 resized pixels per
@@ -790,8 +793,9 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ?
     using RT = typename std::conditional<RBYTES, uint8_t, float>::type;
     constexpr int RP = RPitch<RT, RW>::value;
     constexpr bool LUT_IN_UNI = RBYTES;
-    static_assert(!LUT_IN_UNI || UNI_BYTES >= ((G::SH_BYTES + 15) & ~15) + WB_BIN_LUT_BYTES, "the rank tables fit behind the shrunk tile");
-    constexpr int R_BYTES = LUT_IN_UNI ? RH * RP : (RH * RW * 4 > WB_BIN_LUT_BYTES ? RH * RW * 4 : WB_BIN_LUT_BYTES);   // (float R later holds the rank tables)
+    // (the tables of either width: WB_BIN16_LUT_BYTES is the larger)
+    static_assert(WB_BIN16_LUT_BYTES >= WB_BIN_LUT_BYTES, "table sizes");
+    constexpr int R_BYTES = LUT_IN_UNI ? RH * RP : (RH * RW * 4 > WB_BIN16_LUT_BYTES ? RH * RW * 4 : WB_BIN16_LUT_BYTES);   // (float R later holds the rank tables)
     __shared__ __attribute__((aligned(16))) unsigned char Rraw[R_BYTES];
     RT *R = reinterpret_cast<RT *>(Rraw);
     __shared__ __attribute__((aligned(16))) unsigned char uni[UNI_BYTES];
@@ -954,14 +958,26 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ?
     }
     // rank tables of the model (12 KiB, L2-resident): requested before the barrier, parked in R -- dead once every
     // thread has left step 2 -- right behind it
-    constexpr int LUT_VECS = WB_BIN_LUT_BYTES / 16;
+    constexpr int LUT_VECS = WB_BIN_LUT_BYTES / 16, LUT16_VECS = WB_BIN16_LUT_BYTES / 16;
+    auto ranks_wide_tag = [](const ChanArgs &aa) { return aa.rank != nullptr && aa.rank_wide != 0; };
     static_assert(LUT_VECS == 768 && (NT == 256 || NT == 512), "three vectors per thread (256 threads), one or two (512)");
     const bool ranks = a.rank != nullptr;
-    uint4 lut0 = make_uint4(0, 0, 0, 0), lut1 = lut0, lut2 = lut0;
+    uint4 lut0 = make_uint4(0, 0, 0, 0), lut1 = lut0, lut2 = lut0, lut3 = lut0, lut4 = lut0;
+    const bool wide_lut = ranks_wide_tag(a);
     if (ranks) {
         lut0 = a.rank_lut[tid];
         if (NT == 256 || tid < 256) lut1 = a.rank_lut[tid + NT];
         if (NT == 256) lut2 = a.rank_lut[tid + 512];
+        if (wide_lut) {                                       // (the 16-bit tables: 1280 vectors)
+            static_assert(LUT16_VECS == 1280, "five vectors per thread (256 threads)");
+            if (NT == 256) {
+                lut3 = a.rank_lut[tid + 768];
+                lut4 = a.rank_lut[tid + 1024];
+            } else {
+                if (tid >= 256) lut1 = a.rank_lut[tid + 512];     // 768 .. 1023 (threads 256..511 held nothing there)
+                if (tid < 256) lut2 = a.rank_lut[tid + 1024];     // 1024 .. 1279
+            }
+        }
     }
     __syncthreads();
     if (ranks) {
@@ -969,6 +985,15 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ?
         lut[tid] = lut0;
         if (NT == 256 || tid < 256) lut[tid + NT] = lut1;
         if (NT == 256) lut[tid + 512] = lut2;
+        if (wide_lut) {
+            if (NT == 256) {
+                lut[tid + 768] = lut3;
+                lut[tid + 1024] = lut4;
+            } else {
+                if (tid >= 256) lut[tid + 512] = lut1;
+                if (tid < 256) lut[tid + 1024] = lut2;
+            }
+        }
     }
     WB_CSTAMP(5);
 
@@ -1052,55 +1077,82 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ?
         }
     }
     if (ranks) {
-        // the same pixels as threshold ranks, one dword per pixel (wb_common.h: wb_bin_rank)
-        __syncthreads();                                      // the tables are in R
+        // the same pixels as threshold ranks, one dword per pixel -- or, 16-bit ranks, eight bytes (wb_common.h: wb_bin_rank)
+        __syncthreads();                                      // the tables are in LDS
         const float *Sthr = reinterpret_cast<const float *>(lut_lds);
-        const uint8_t *base = reinterpret_cast<const uint8_t *>(lut_lds) + 4 * WB_BIN_SLOTS * 4;
-        uint32_t *rout = reinterpret_cast<uint32_t *>(a.rank + (int64_t)b * a.rank_stride + L.chn_off);
         const int K = a.rank_iters;
-        // all RPT x 4 values of the thread advance together: every step is RPT * 4 independent LDS lookups (one
-        // value at a time, the 1 + K dependent lookups of each value were a chain of LDS latencies)
-        uint32_t r[RPT][4];
-        if (live) {
-#pragma unroll
-            for (int y = 0; y < RPT; ++y)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) r[y][k] = base[k * WB_BIN_CELLS + wb_bin_cell(o[y][k], a.rank_k[k], a.rank_b[k])];
-            if (K <= 2) {
-                // the usual case -- at most two thresholds share a cell: both candidates S[r], S[r + 1] come with ONE
-                // LDS read (they are neighbours) and are compared independently: S is sorted, so the second test only
-                // passes where the first does; a threshold of a higher cell, or the +inf padding, never passes
-                // (r + 1 <= WB_BIN_MAX stays inside the channel's table)
+        auto rank_pixels = [&](auto wide_tag) {
+            constexpr bool WIDE = decltype(wide_tag)::value;
+            constexpr int SLOTS = WIDE ? WB_BIN16_SLOTS : WB_BIN_SLOTS, CELLS = WIDE ? WB_BIN16_CELLS : WB_BIN_CELLS;
+            const uint8_t *base8 = reinterpret_cast<const uint8_t *>(lut_lds) + 4 * SLOTS * 4;
+            const uint16_t *base16 = reinterpret_cast<const uint16_t *>(base8);
+            // all RPT x 4 values of the thread advance together: every step is RPT * 4 independent LDS lookups (one
+            // value at a time, the 1 + K dependent lookups of each value were a chain of LDS latencies)
+            uint32_t r[RPT][4];
+            if (live) {
 #pragma unroll
                 for (int y = 0; y < RPT; ++y)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float *sp = Sthr + k * WB_BIN_SLOTS + r[y][k];
-                        const float s0 = sp[0], s1 = sp[1];
-                        r[y][k] += (o[y][k] > s0 ? 1u : 0u) + (o[y][k] > s1 ? 1u : 0u);
+                        const uint32_t cell = wb_bin_cell(o[y][k], a.rank_k[k], a.rank_b[k], (float)(CELLS - 1));
+                        r[y][k] = WIDE ? (uint32_t)base16[k * CELLS + cell] : (uint32_t)base8[k * CELLS + cell];
                     }
-            } else {
-                for (int i = 0; i < K; ++i) {
+                if (K <= 2) {
+                    // the usual case -- at most two thresholds share a cell: both candidates S[r], S[r + 1] come with ONE
+                    // LDS read (they are neighbours) and are compared independently: S is sorted, so the second test only
+                    // passes where the first does; a threshold of a higher cell, or the +inf padding, never passes
+                    // (r + 1 <= the table's last padding slot stays inside the channel's table)
 #pragma unroll
                     for (int y = 0; y < RPT; ++y)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) r[y][k] += o[y][k] > Sthr[k * WB_BIN_SLOTS + r[y][k]] ? 1u : 0u;
+                        for (int k = 0; k < 4; ++k) {
+                            const float *sp = Sthr + k * SLOTS + r[y][k];
+                            const float s0 = sp[0], s1 = sp[1];
+                            r[y][k] += (o[y][k] > s0 ? 1u : 0u) + (o[y][k] > s1 ? 1u : 0u);
+                        }
+                } else if (WIDE && K <= 4) {
+                    // the coarser 16-bit grid: up to four thresholds per cell, all four candidates S[r .. r + 3] fetched at
+                    // once (r + 3 <= 1023: the table's last four slots are +inf padding)
+#pragma unroll
+                    for (int y = 0; y < RPT; ++y)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float *sp = Sthr + k * SLOTS + r[y][k];
+                            const float s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+                            r[y][k] += (o[y][k] > s0 ? 1u : 0u) + (o[y][k] > s1 ? 1u : 0u) + (o[y][k] > s2 ? 1u : 0u) + (o[y][k] > s3 ? 1u : 0u);
+                        }
+                } else {
+                    for (int i = 0; i < K; ++i) {
+#pragma unroll
+                        for (int y = 0; y < RPT; ++y)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) r[y][k] += o[y][k] > Sthr[k * SLOTS + r[y][k]] ? 1u : 0u;
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int y = 0; y < RPT; ++y) {
-            const int su = u0 + i0 + y;
-            if (!live || su >= L.u || sv >= L.v || (a.dbg & 4)) continue;
-            uint32_t w = 0;
+            for (int y = 0; y < RPT; ++y) {
+                const int su = u0 + i0 + y;
+                if (!live || su >= L.u || sv >= L.v || (a.dbg & 4)) continue;
+                uint32_t rk[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t rk = r[y][k];
-                if constexpr (sizeof(T) != 1) rk = o[y][k] != o[y][k] ? 255u : rk;      // a NaN pixel fails every `v <= thr`
-                w |= rk << (8 * k);
+                for (int k = 0; k < 4; ++k) {
+                    rk[k] = r[y][k];
+                    if constexpr (sizeof(T) != 1) rk[k] = o[y][k] != o[y][k] ? (WIDE ? 65535u : 255u) : rk[k];   // a NaN pixel fails every `v <= thr`
+                }
+                if constexpr (WIDE) {
+                    uint2 *rout = reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.rank) + ((int64_t)b * a.rank_stride + L.chn_off));
+                    rout[(int64_t)su * L.v + sv] = make_uint2(rk[0] | (rk[1] << 16), rk[2] | (rk[3] << 16));
+                } else {
+                    uint32_t *rout = reinterpret_cast<uint32_t *>(a.rank + (int64_t)b * a.rank_stride + L.chn_off);
+                    rout[(int64_t)su * L.v + sv] = rk[0] | (rk[1] << 8) | (rk[2] << 16) | (rk[3] << 24);
+                }
             }
-            rout[(int64_t)su * L.v + sv] = w;
-        }
+        };
+        if (a.rank_wide)
+            rank_pixels(std::true_type{});
+        else
+            rank_pixels(std::false_type{});
     }
     WB_CSTAMP(7);
 }
@@ -1775,7 +1827,7 @@ extern "C" int wb_channels_launch(void *stream, const void *img, int64_t img_str
                                   uint8_t *rank, int64_t rank_stride) {
     return wb_channels_launch_x(stream, img, img_stride, oct, oct_stride, dtype, batch, levels, n_levels, tiles, n_tiles, minmax,
                                 n_oct, taps, channel_func, shrink, smooth, cs_sn, chn, chn_stride, rank_model, rank, rank_stride,
-                                nullptr);
+                                nullptr, WB_DTYPE_RANK8);
 }
 
 extern "C" int wb_channels_launch_x(void *stream, const void *img, int64_t img_stride, const void *oct,
@@ -1783,13 +1835,17 @@ extern "C" int wb_channels_launch_x(void *stream, const void *img, int64_t img_s
                                     int n_levels, const WbTile *tiles, int n_tiles, const uint32_t *minmax,
                                     int n_oct, const WbTap *taps, int channel_func, int shrink, int smooth,
                                     const double *cs_sn, void *chn, int64_t chn_stride, const WbModel *rank_model,
-                                    uint8_t *rank, int64_t rank_stride, const WbTilePatch *patches) {
+                                    uint8_t *rank, int64_t rank_stride, const WbTilePatch *patches, int rank_dtype) {
     WB_REQUIRE(img && levels && tiles && minmax && taps && (chn || rank), "wb_channels_launch: null pointer");
+    WB_REQUIRE(!rank || rank_dtype == WB_DTYPE_RANK8 || rank_dtype == WB_DTYPE_RANK16, "wb_channels_launch_x: rank_dtype %d (WB_DTYPE_RANK8 or WB_DTYPE_RANK16)", rank_dtype);
+    const bool wide = rank && rank_dtype == WB_DTYPE_RANK16;
+    WB_REQUIRE(!wide || rank_model->bin16_ok, "wb_channels_launch_x: this model has no 16-bit rank tables (wb_model_info: rank16_ok)");
+    WB_REQUIRE(!wide || reinterpret_cast<uintptr_t>(rank) % 8 == 0, "wb_channels_launch_x: 16-bit ranks must be 8-byte aligned");
     WB_REQUIRE(!patches || (dtype == WB_DTYPE_U8 && channel_func != WB_CHN_GRAD_MAG),
                "wb_channels_launch_x: the patch table goes with uint8 images and the gradient-histogram kernels");
     WB_REQUIRE(!rank == !rank_model, "wb_channels_launch: rank and rank_model go together");
     WB_REQUIRE(!rank || channel_func == WB_CHN_GRAD_HIST, "wb_channels_launch: ranks are written for grad_hist channels only");
-    WB_REQUIRE(!rank || rank_model->bin_ok, "wb_channels_launch: this model has no rank tables (wb_model_info: rank_ok)");
+    WB_REQUIRE(!rank || wide || rank_model->bin_ok, "wb_channels_launch: this model has no rank tables (wb_model_info: rank_ok)");
     WB_REQUIRE(!rank || reinterpret_cast<uintptr_t>(rank) % 4 == 0, "wb_channels_launch: rank must be 4-byte aligned");
     WB_REQUIRE(cs_sn || channel_func != WB_CHN_GRAD_HIST, "wb_channels_launch: grad_hist needs the orientation constants");
     WB_REQUIRE(batch >= 1 && n_levels >= 1 && n_tiles >= 1, "wb_channels_launch: empty launch");
@@ -1814,12 +1870,13 @@ extern "C" int wb_channels_launch_x(void *stream, const void *img, int64_t img_s
     a.rank_lut = nullptr;
     a.rank_iters = 0;
     a.patches = patches;
+    a.rank_wide = wide ? 1 : 0;
     if (rank) {
-        a.rank_lut = reinterpret_cast<const uint4 *>(rank_model->bin_lut_dev);
-        a.rank_iters = rank_model->bin_iters;
+        a.rank_lut = reinterpret_cast<const uint4 *>(wide ? rank_model->bin16_lut_dev : rank_model->bin_lut_dev);
+        a.rank_iters = wide ? rank_model->bin16_iters : rank_model->bin_iters;
         for (int k = 0; k < 4; ++k) {
-            a.rank_k[k] = rank_model->bin_k[k];
-            a.rank_b[k] = rank_model->bin_b[k];
+            a.rank_k[k] = wide ? rank_model->bin16_k[k] : rank_model->bin_k[k];
+            a.rank_b[k] = wide ? rank_model->bin16_b[k] : rank_model->bin_b[k];
         }
     }
     if (cs_sn) set_constants(a, cs_sn);

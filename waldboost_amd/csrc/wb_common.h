@@ -75,6 +75,14 @@ __device__ inline double wb_round_f16(double x) {
 #define WB_BIN_SLOTS 256     // entries of a channel's sorted threshold table
 #define WB_BIN_CELLS 2048    // cells of a channel's lookup grid
 #define WB_BIN_LUT_BYTES (4 * WB_BIN_SLOTS * 4 + 4 * WB_BIN_CELLS)   // float S[4][256], then uint8 base[4][N]
+// ... and in two bytes (WB_DTYPE_RANK16): cascades with more distinct thresholds per channel than a byte ranks -- long soft
+// cascades (reference __init__.py:230-269 appends stages without bound), deep trees.  The tables still live in LDS while
+// a channel tile is ranked, so the count is bounded by that: 1020 thresholds per channel (S[1020..1023] = +inf padding: the
+// channel kernel reads S[r .. r + 3] together), 512 grid cells with 16-bit base counts = 20 KiB.
+#define WB_BIN16_MAX 1020
+#define WB_BIN16_SLOTS 1024
+#define WB_BIN16_CELLS 512
+#define WB_BIN16_LUT_BYTES (4 * WB_BIN16_SLOTS * 4 + 4 * WB_BIN16_CELLS * 2)   // float S[4][1024], then uint16 base[4][512]
 
 // The canonical stage record the cascade kernels read with scalar loads:
 //   int   off[NI]   LDS byte offset of each internal node's feature (BFS order)
@@ -110,6 +118,14 @@ struct WbModel {
     int bin_lut_vec;            // size of the table block in 16-byte units
     uint8_t *bin_lut_dev;       // float S[4][256] (sorted thresholds, +inf padded), then uint8 base[4][N]
     int32_t *stages_bin_dev;    // stage records for the binned tile: byte-tile offsets, thresholds = ranks
+    // the same with 16-bit ranks (WB_DTYPE_RANK16): up to WB_BIN16_MAX distinct thresholds per channel
+    int bin16_ok, bin16_iters;
+    float bin16_k[4], bin16_b[4];
+    uint8_t *bin16_lut_dev;     // float S[4][WB_BIN16_SLOTS], then uint16 base[4][WB_BIN16_CELLS]
+    int32_t *stages_bin16_dev;  // stage records for the 16-bit tile [rows][pitch][C] x 2 bytes: byte offsets, thresholds = ranks
+    int32_t *stages_bin16_host;
+    int lds_bytes_u16;          // dynamic LDS of the kernel on the 16-bit tile
+    void *jit_bin16;
     // host copy of the caller's tree arrays (wb_rankgroup_create derives stage records for a shared rank table from them)
     int n_nodes;
     int32_t *h_node_off;        // [n_stages + 1]
@@ -133,8 +149,8 @@ struct WbModel {
 
 // ---- threshold ranks of float32 channel values (WbModel::bin_*, WB_DTYPE_RANK8) ----
 // cell of a channel's lookup grid (host mirror: bin_cell() in wb_api.hip): non-decreasing in v
-__device__ inline uint32_t wb_bin_cell(float v, float k, float b) {
-    const float q = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, k, b), 0.0f, (float)(WB_BIN_CELLS - 1));
+__device__ inline uint32_t wb_bin_cell(float v, float k, float b, float top = (float)(WB_BIN_CELLS - 1)) {
+    const float q = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, k, b), 0.0f, top);
     return (uint32_t)q;
 }
 // rank of v among the channel's sorted distinct thresholds S (+inf padded): the number of them below v.

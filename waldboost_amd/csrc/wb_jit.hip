@@ -48,18 +48,24 @@ uint64_t fnv1a(const void *p, size_t n, uint64_t h = 1469598103934665603ull) {
 
 // the stage segments run_segments walks for a cascade of T stages (wb_cascade_tile.h: t_end = min(2 t, T, t + 64),
 // from stage 8 on; the re-count at stage 16 splits nothing: 16 is on the chain)
+// Only the segments that end by stage WB_JIT_BAKE_STAGES (default 384) are unrolled with their records as constants: the
+// windows of a long soft cascade that get that far are a handful per tile, and a wave that walks them streams through its
+// code once -- unrolled, stages 384..1023 would be hundreds of KB of instructions nobody executes twice; they run the
+// generic segment loop of the same kernel (records through the scalar cache).
 std::string segment_list(int T) {
+    static const int cap = getenv("WB_JIT_BAKE_STAGES") ? atoi(getenv("WB_JIT_BAKE_STAGES")) : 384;
     std::string s;
     for (int t = 8; t < T;) {
         int e = 2 * t < T ? 2 * t : T;
         e = e < t + 64 ? e : t + 64;
+        if (e > cap && t >= 16) break;
         s += " X(" + std::to_string(t) + "," + std::to_string(e) + ")";
         t = e;
     }
     return s;
 }
 
-std::string make_source(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch) {
+std::string make_source(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch, int eb = 1, int lds_stages = -1) {
     std::string s;
     s.reserve(n_words * 12 + 1024);
     s += "#define WB_JIT_BAKED 1\n#define WB_JIT_STAGE_WORDS ";
@@ -68,6 +74,7 @@ std::string make_source(const int32_t *words, size_t n_words, int T, int D, int 
         s += std::to_string(words[i]);
     }
     s += "\n#define WB_JIT_SEGMENTS(X)" + segment_list(T) + "\n";
+    s += "#define WB_JIT_LDS_STAGES " + std::to_string(lds_stages < 0 ? T : lds_stages) + "\n";
     s += "#define WB_JIT_T " + std::to_string(T) + "\n#define WB_JIT_C " + std::to_string(C) + "\n#define WB_JIT_ROWS " +
          std::to_string(rows) + "\n#define WB_JIT_PITCH " + std::to_string(pitch) + "\n";
     s += "#include \"wb_cascade_tile.h\"\n";
@@ -75,7 +82,7 @@ std::string make_source(const int32_t *words, size_t n_words, int T, int D, int 
     s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(waves * 64) +
          ") __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void wb_casc_jit(CascArgs a, const int32_t *stages) {\n"
          "    cascade_tile_body<" + std::to_string(D) + ", " + std::to_string(rpw) + ", " + std::to_string(waves) +
-         ", true, true>(a, stages);\n}\n";
+         ", " + std::to_string(eb) + ", true>(a, stages);\n}\n";
     return s;
 }
 
@@ -172,13 +179,14 @@ int compile(const std::string &src, const char *arch, std::vector<char> &code, s
 }  // namespace
 
 // Build (or fetch) the specialised kernel for one stage table of `M`.  words: (T + G) records of SD dwords as uploaded.
-int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch, void **func_out) {
+int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch, int eb, int lds_stages,
+               void **func_out) {
     *func_out = nullptr;
     hipDeviceProp_t prop;
     int dev = 0;
     WB_HIP_CHECK(hipGetDevice(&dev));
     WB_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    const std::string src = make_source(words, n_words, T, D, rpw, waves, C, rows, pitch);
+    const std::string src = make_source(words, n_words, T, D, rpw, waves, C, rows, pitch, eb, lds_stages);
     int rtc_major = 0, rtc_minor = 0;
     (void)hiprtcVersion(&rtc_major, &rtc_minor);
     uint64_t h = fnv1a(src.data(), src.size());
@@ -222,8 +230,12 @@ int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int 
 // Compile check without a GPU (the CPU test suite): a synthetic cascade of n_stages random depth-`depth` trees through
 // the same generator and hiprtc for `arch`.  Returns the code object's size in *code_bytes.
 extern "C" int wb_jit_compile_check(int depth, int n_stages, const char *arch, int64_t *code_bytes) {
-    WB_REQUIRE(depth >= 1 && depth <= WB_CASC_MAX_DEPTH && n_stages >= 1 && n_stages <= 4096 && arch && code_bytes,
-               "wb_jit_compile_check: bad argument");
+    return wb_jit_compile_check2(depth, n_stages, 1, arch, code_bytes);
+}
+
+extern "C" int wb_jit_compile_check2(int depth, int n_stages, int elem_bytes, const char *arch, int64_t *code_bytes) {
+    WB_REQUIRE(depth >= 1 && depth <= WB_CASC_MAX_DEPTH && n_stages >= 1 && n_stages <= 4096 && arch && code_bytes &&
+               (elem_bytes == 1 || elem_bytes == 2), "wb_jit_compile_check: bad argument");
     const int SD = WB_STAGE_DWORDS(depth), NI = WB_STAGE_NI(depth), NL = WB_STAGE_NL(depth), G = wb_cascade_group(depth);
     std::vector<int32_t> words((size_t)(n_stages + G) * SD, 0);
     uint32_t x = 12345u;
@@ -236,13 +248,15 @@ extern "C" int wb_jit_compile_check(int depth, int n_stages, const char *arch, i
             continue;
         }
         for (int i = 0; i < NI; ++i) {
-            rec[i] = (int32_t)(rnd() % 3000u);
-            rec[NI + i] = (int32_t)(rnd() % 255u);
+            rec[i] = (int32_t)(rnd() % 3000u) * elem_bytes;
+            rec[NI + i] = (int32_t)(rnd() % (elem_bytes == 2 ? 1000u : 255u));
         }
         for (int i = 0; i < NL; ++i) f[2 * NI + i] = (float)(rnd() % 2000u) * 1e-3f - 1.0f;
         f[2 * NI + NL] = s % 7 == 3 ? -INFINITY : -0.5f * (float)s;
     }
-    const std::string src = make_source(words.data(), words.size(), n_stages, depth, 4, 8, 4, 4 * 8 + 11, WB_CASC_TC + 12);
+    // (as wb_model_create decides it: a stage table beyond 16 KiB is not mirrored in LDS)
+    const int lds_stages = n_stages * SD * 4 <= 16 * 1024 ? n_stages : 0;
+    const std::string src = make_source(words.data(), words.size(), n_stages, depth, 4, 8, 4, 4 * 8 + 11, WB_CASC_TC + 12, elem_bytes, lds_stages);
     std::vector<char> code;
     std::string log;
     const int rc = compile(src, arch, code, log);

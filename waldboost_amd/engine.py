@@ -51,6 +51,7 @@ _NO_RANKS = bool(os.environ.get("WB_NO_RANKS"))     # diagnostic: float32 channe
 _NO_FUSED_RESET = bool(os.environ.get("WB_NO_FUSED_RESET"))   # diagnostic: one memset launch per step, as before
 _JIT_AUTO = os.environ.get("WB_CASC_JIT", "1") != "0"
 _JIT_AFTER = int(os.environ.get("WB_CASC_JIT_AFTER", "3"))
+_FORCE_RANK16 = bool(os.environ.get("WB_FORCE_RANK16"))   # diagnostic / bench: 16-bit ranks also where a byte would do
 
 
 def _torch_dtype(np_dtype):
@@ -169,6 +170,11 @@ class DeviceCascade:
         # the model's thresholds fit rank tables: the channel kernel can write float32 channels as one-byte ranks
         # (WB_DTYPE_RANK8) and the cascade scan them exactly as it would the floats, from a quarter of the bytes
         self.rank_ok = bool(info.rank_ok)
+        # ... or, with more thresholds per channel than a byte ranks (long soft cascades), as two-byte ranks (WB_DTYPE_RANK16)
+        self.rank16_ok = bool(info.rank16_ok)
+        # the rank form the detection path uses for this cascade (None: float32 channels)
+        self.rank_dtype = (nat.WB_DTYPE_RANK16 if (self.rank16_ok and (_FORCE_RANK16 or not self.rank_ok)) else
+                           nat.WB_DTYPE_RANK8 if self.rank_ok else None)
 
     @classmethod
     def _view(cls, handle, group):
@@ -184,17 +190,17 @@ class DeviceCascade:
         return self
 
     def specialized(self):
-        """Which byte tiles have a model-specialised kernel loaded: subset of {WB_DTYPE_U8, WB_DTYPE_RANK8}."""
+        """Which byte tiles have a model-specialised kernel loaded: subset of {WB_DTYPE_U8, WB_DTYPE_RANK8, WB_DTYPE_RANK16}."""
         info = nat.WbModelInfo()
         nat.check(self._lib.wb_model_info(self.handle, C.byref(info)), "wb_model_info")
-        return {d for bit, d in ((1, nat.WB_DTYPE_U8), (2, nat.WB_DTYPE_RANK8)) if info.specialized & bit}
+        return {d for bit, d in ((1, nat.WB_DTYPE_U8), (2, nat.WB_DTYPE_RANK8), (4, nat.WB_DTYPE_RANK16)) if info.specialized & bit}
 
     def specialize(self, chn_dtype=None):
         """Compile and load the model-specialised tile kernel (wb_model_specialize) for a kind of byte tile: the threshold
         ranks by default when the model has rank tables, else uint8 channels.  Returns False when this model has no
         specialised kernel (node-walk models, cascades beyond the LDS mirror); raises NativeError if the compiler fails."""
         if chn_dtype is None:
-            chn_dtype = nat.WB_DTYPE_RANK8 if self.rank_ok else nat.WB_DTYPE_U8
+            chn_dtype = self.rank_dtype if self.rank_dtype is not None else nat.WB_DTYPE_U8
         rc = self._lib.wb_model_specialize(self.handle, chn_dtype)
         if rc == nat.WB_ERR_UNSUPPORTED:
             return False
@@ -421,6 +427,7 @@ class PyramidEngine:
         self.cs_sn = orientation_constants()
         self._oct_off = (C.c_int64 * max(p.n_oct, 1))(*[int(x) for x in p.oct_off[:max(p.n_oct, 1)]])
         self.rank = self._rank_flat = self.rank_owner = None
+        self._rank_wide = False
         self._level_tiles = None
         self.epoch = 0
         self.det_capacity = int(det_capacity)
@@ -615,7 +622,7 @@ class PyramidEngine:
     def ranks_for(self, dm):
         """True when the fused detection path applies: grad_hist channels written straight as threshold ranks of
         cascade `dm` (float32 channels never reach HBM)."""
-        return dm is not None and dm.rank_ok and self.spec.key == "grad_hist" and not _NO_RANKS
+        return dm is not None and dm.rank_dtype is not None and self.spec.key == "grad_hist" and not _NO_RANKS
 
     def launch_channels(self, rank_dm=None, floats=True):
         """The channel pyramid of every resident image.  rank_dm: also (floats=False: only) write the channels as
@@ -624,9 +631,17 @@ class PyramidEngine:
         p = self.plan
         if p.n_levels == 0:
             return
-        if rank_dm is not None and self.rank is None:
-            self._rank_flat = torch.zeros(self.batch * self.chn_stride + 16, dtype=torch.uint8, device=self.dev)
+        wide = rank_dm is not None and rank_dm.rank_dtype == nat.WB_DTYPE_RANK16
+        if rank_dm is not None and (self.rank is None or self._rank_wide != wide):
+            # one byte per value, or two (WB_DTYPE_RANK16); 16 spare elements for the cascade's 16-byte group loads
+            tdt = torch.int16 if wide else torch.uint8
+            self._rank_flat = torch.zeros(self.batch * self.chn_stride + 16, dtype=tdt, device=self.dev)
             self.rank = self._rank_flat[: self.batch * self.chn_stride].view(self.batch, self.chn_stride)
+            self._rank_wide = wide
+            self.generation += 1          # (captured graphs address the old buffer)
+            for stt in self._casc.values():
+                stt.pop("graph", None)
+                stt.pop("step", None)
         nat.check(self.lib.wb_channels_launch_x(nat.stream_ptr(), nat.ptr(self.img), p.H * p.W, nat.ptr(self.oct),
                                                 p.oct_total, self.wb_dtype, self.batch, nat.ptr(self.levels),
                                                 p.n_levels, nat.ptr(self.chan_tiles), self.n_chan_tiles,
@@ -636,7 +651,8 @@ class PyramidEngine:
                                                 nat.ptr(self.chn if floats or rank_dm is None else None), self.chn_stride,
                                                 rank_dm.handle if rank_dm is not None else None,
                                                 nat.ptr(self.rank if rank_dm is not None else None), self.chn_stride,
-                                                nat.ptr(self.chan_patches)),
+                                                nat.ptr(self.chan_patches),
+                                                rank_dm.rank_dtype if rank_dm is not None else nat.WB_DTYPE_RANK8),
                   "wb_channels_launch")
         self.rank_owner = rank_dm.rank_key if rank_dm is not None else None      # whose ranks self.rank holds (None: stale)
 
@@ -662,7 +678,8 @@ class PyramidEngine:
                                                 nat.ptr(self.minmax), max(p.n_oct, 1), nat.ptr(self.taps),
                                                 self.spec.func_id, p.shrink, p.smooth,
                                                 self.cs_sn.ctypes.data_as(C.POINTER(C.c_double)),
-                                                nat.ptr(self.chn), self.chn_stride, None, None, 0, nat.ptr(patches_d)),
+                                                nat.ptr(self.chn), self.chn_stride, None, None, 0, nat.ptr(patches_d),
+                                                nat.WB_DTYPE_RANK8),
                   "wb_channels_launch")
 
 
@@ -726,10 +743,10 @@ class PyramidEngine:
             return stt
         if ranks and self.rank_owner is not dm.rank_key:
             raise RuntimeError("the rank buffer does not hold this cascade's ranks (launch_channels(rank_dm=...) first)")
-        dm.note_scan(nat.WB_DTYPE_RANK8 if ranks else self.spec.wb_dtype)
+        dm.note_scan(dm.rank_dtype if ranks else self.spec.wb_dtype)
         zk = self.ctrl[: self._mm_words] if zero_keys else None
         nat.check(self.lib.wb_cascade_launch_z(nat.stream_ptr(), dm.handle, nat.ptr(self.rank if ranks else self.chn),
-                                               nat.WB_DTYPE_RANK8 if ranks else self.spec.wb_dtype,
+                                               dm.rank_dtype if ranks else self.spec.wb_dtype,
                                                self.chn_stride,
                                                self.batch, nat.ptr(self.levels), self.plan.n_levels,
                                                nat.ptr(stt["tiles"]), stt["n_tiles"],
@@ -1055,7 +1072,7 @@ class PyramidEngine:
         if g is None and stt.get("detect_calls", 0) >= 1 and not _NO_DETECT_GRAPH:
             # (the first call ran eagerly: every lazily allocated buffer exists, the kernels are loaded)
             # a cascade that is scanned again is worth its specialised kernel -- built now, so that the graph holds it
-            dm.note_scan(nat.WB_DTYPE_RANK8 if self.ranks_for(dm) else self.spec.wb_dtype, force=True)
+            dm.note_scan(dm.rank_dtype if self.ranks_for(dm) else self.spec.wb_dtype, force=True)
             g = torch.cuda.CUDAGraph()
             self.ensure_clean_keys()          # (the captured step holds no memset: see run)
             torch.cuda.synchronize()
@@ -1081,7 +1098,7 @@ class PyramidEngine:
         if step is not None and step.generation != self.generation:
             step = None
         if step is None and stt.get("batch_calls", 0) >= 1 and not _NO_DETECT_GRAPH:
-            dm.note_scan(nat.WB_DTYPE_RANK8 if self.ranks_for(dm) else self.spec.wb_dtype, force=True)
+            dm.note_scan(dm.rank_dtype if self.ranks_for(dm) else self.spec.wb_dtype, force=True)
             step = stt["step"] = self.capture(dm)
         stt["batch_calls"] = stt.get("batch_calls", 0) + 1
         if step is None:
@@ -1121,7 +1138,7 @@ class PyramidEngine:
         if st["graph"] is None and st["calls"] >= 1 and st["fails"] == 0 and not _NO_DETECT_GRAPH:
             # (captured after an eager call whose results fitted: a sequence that keeps missing is not worth a capture)
             for d in dms:
-                d.note_scan(nat.WB_DTYPE_RANK8 if ranks else self.spec.wb_dtype, force=True)
+                d.note_scan(d.rank_dtype if ranks else self.spec.wb_dtype, force=True)
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             with capturing(g):
@@ -1195,7 +1212,8 @@ class PyramidEngine:
         lv = self.plan.levels[l]
         off = int(self.level_np[l]["chn_off"])
         u, v = lv["u"], lv["v"]
-        return self.rank[b, off:off + u * v * 4].reshape(u, v, 4).cpu().numpy()
+        r = self.rank[b, off:off + u * v * 4].reshape(u, v, 4).cpu().numpy()
+        return r.view(np.uint16) if r.dtype == np.int16 else r
 
     def read_level(self, b, l):
         """Channels of level l of image b as a fresh HWC ndarray [u,v,C] of the channel function's dtype."""
