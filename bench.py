@@ -747,7 +747,7 @@ def main():
         n3 = args.config3_images
         shard = torch.from_numpy(cfg3_host).to(engines[0].dev)                  # this rank's images, resident
         del cfg3_host
-        walls, scans, dets = [], [], None
+        walls, scans, phases, dets = [], [], [], None
         for rep in range(4):                                  # the first call is untimed: buffers, graphs, capacity growth
             torch.cuda.synchronize()
             dist.barrier()
@@ -757,12 +757,15 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
-            dt3 = torch.tensor([time.perf_counter() - t0, wbd.LAST_TIMING.get("scan_s", 0.0)], dtype=torch.float64, device=cdev)
-            allt = torch.zeros((world, 2), dtype=torch.float64, device=cdev)
-            dist.all_gather_into_tensor(allt, dt3.view(1, 2))
+            lt = wbd.LAST_TIMING
+            dt3 = torch.tensor([time.perf_counter() - t0, lt.get("scan_s", 0.0), lt.get("agree_s", 0.0), lt.get("order_s", 0.0),
+                                lt.get("gather_s", 0.0)], dtype=torch.float64, device=cdev)
+            allt = torch.zeros((world, 5), dtype=torch.float64, device=cdev)
+            dist.all_gather_into_tensor(allt, dt3.view(1, 5))
             if rep:
                 walls.append(float(allt[:, 0].max()))
                 scans.append([float(x) for x in allt[:, 1].tolist()])
+                phases.append([[round(float(x) * 1e3, 3) for x in allt[r, 2:].tolist()] for r in range(world)])
         if rank == 0:
             wall3 = float(np.median(walls))
             # rank 0's merged result against the single-image entry point, Model.detect_raw, for the first, the middle and
@@ -787,6 +790,8 @@ def main():
                 "wall_ms": wall3 * 1e3, "wall_ms_all": [round(w * 1e3, 3) for w in walls], "calls_timed": len(walls), "calls_untimed": 1,
                 "windows_per_s": n3 * n_loc / wall3, "images_per_s": n3 / wall3, "scaling": "strong (the batch is fixed, the ranks share it)",
                 "per_rank_scan_ms": [round(x * 1e3, 3) for x in scans[int(np.argsort(walls)[len(walls) // 2])]],
+                "per_rank_exchange_ms": {"columns": ["agree_capacity", "order on the device", "gather + read-back"],
+                                         "rows": phases[int(np.argsort(walls)[len(walls) // 2])]},
                 "detections": int(det3.size), "n_weak": int(total3.sum()), "eval_cost": float(total3.sum()) / (n3 * n_loc),
                 "check": {"against": "Model.detect_raw per image (level, r, c, score bits)", "images": checked, "bit_exact": True},
                 "host_prep_s": round(t_gen, 2),

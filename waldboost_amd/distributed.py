@@ -158,22 +158,17 @@ def agree_capacity(scan, group=None):
         rounds += 1
 
 
-_PINNED = {}
-
-
 def _to_host(t):
-    """A device int32 [n, 4] tensor as a host ndarray through a cached page-locked buffer (25 MB of records take ~1 ms this
-    way, several from pageable memory)."""
+    """A device int32 [n, 4] tensor as a host ndarray that OWNS page-locked memory from torch's caching host allocator: one
+    DMA, no second copy on the host (25 MB of records: ~1 ms; through a reused staging buffer the copy out of it cost
+    another 2.5 ms).  The block goes back to the allocator's cache when the array is dropped."""
     import torch
     if t.device.type != "cuda":
         return t.numpy()
-    n = t.shape[0]
-    buf = _PINNED.get("recs")
-    if buf is None or buf.shape[0] < n:
-        buf = _PINNED["recs"] = torch.empty((max(n, 1 << 16), 4), dtype=torch.int32).pin_memory()
-    buf[:n].copy_(t, non_blocking=True)
+    buf = torch.empty(tuple(t.shape), dtype=t.dtype, pin_memory=True)
+    buf.copy_(t, non_blocking=True)
     torch.cuda.current_stream().synchronize()
-    return buf[:n].numpy()
+    return buf.numpy()                                             # (the array keeps the tensor's storage alive)
 
 
 def gather_records(recs, n_images, group=None, dst=0, first_image=None, presorted=False):
@@ -209,15 +204,23 @@ def gather_records(recs, n_images, group=None, dst=0, first_image=None, presorte
         first_image = np.concatenate([[0], np.cumsum(meta[:-1, 1])])
     counts = [int(meta[r, 0]) for r in range(world)]
     if all(bf.device.type == "cuda" for bf in bufs) and sum(counts):
-        allr = torch.cat([bufs[r][: counts[r]] for r in range(world)]) if world > 1 else bufs[0][: counts[0]]
-        host = _to_host(allr).copy()                           # ONE read-back of all ranks' records
+        # image indices made global on the device (rank r's block + first_image[r]), then ONE read-back of all ranks' records
+        parts = []
+        for r in range(world):
+            blk = bufs[r][: counts[r]]
+            if counts[r] and int(first_image[r]):
+                blk = blk.clone() if world == 1 else blk       # (never the caller's own tensor)
+                blk[:, 0] += int(first_image[r])
+            parts.append(blk)
+        allr = torch.cat(parts) if world > 1 else parts[0]
+        out = np.ascontiguousarray(_to_host(allr)).view(DET_DTYPE).reshape(-1)
     else:
         host = np.concatenate([bufs[r][: counts[r]].cpu().numpy() for r in range(world)]) if world else np.zeros((0, 4), np.int32)
-    out = np.ascontiguousarray(host).view(DET_DTYPE).reshape(-1)
-    at = 0
-    for r in range(world):
-        out["image"][at: at + counts[r]] += int(first_image[r])
-        at += counts[r]
+        out = np.ascontiguousarray(host).view(DET_DTYPE).reshape(-1)
+        at = 0
+        for r in range(world):
+            out["image"][at: at + counts[r]] += int(first_image[r])
+            at += counts[r]
     if presorted and contiguous:
         return out
     return out[np.lexsort((out["c"], out["r"], out["level"], out["image"]))]
@@ -396,8 +399,17 @@ def detect_sharded(model, images, group=None, dst=0, batch=64, per_image_alive=T
     LAST_TIMING.clear()
     LAST_TIMING["scan_s"] = time.perf_counter() - t0      # this rank's own scan, up to its one synchronisation
     agree_capacity(scan, group)
+    LAST_TIMING["agree_s"] = time.perf_counter() - t0 - LAST_TIMING["scan_s"]
     L = plan.n_levels
-    det = gather_records(scan.records(), b, group, dst, presorted=True)
+    t1 = time.perf_counter()
+    recs = scan.records()
+    if recs.device.type == "cuda":
+        import torch
+        torch.cuda.current_stream().synchronize()
+    LAST_TIMING["order_s"] = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    det = gather_records(recs, b, group, dst, presorted=True)
+    LAST_TIMING["gather_s"] = time.perf_counter() - t1
     alive = None
     if per_image_alive:
         alive = (scan.alive_d[:, :, :T].cpu().numpy().astype(np.int64) if b else np.zeros((0, L, T), np.int64)).reshape(b, L, T)
