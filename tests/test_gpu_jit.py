@@ -31,7 +31,7 @@ def both_kernels(M, img):
     assert not dm.specialized()
     assert_same(M.detect_raw(img), ref)                     # generic kernel (first scan)
     assert dm.specialize()
-    kind = nat.WB_DTYPE_RANK8 if dm.rank_ok else nat.WB_DTYPE_U8
+    kind = dm.rank_dtype if dm.rank_dtype is not None else nat.WB_DTYPE_U8
     assert kind in dm.specialized()
     for _ in range(2):                                      # eager, then the captured graph of Model.detect
         assert_same(M.detect_raw(img), ref)
@@ -72,6 +72,27 @@ def test_specialised_kernel_on_random_cascades_of_every_length_and_depth(seed, T
                      func=wb.channels.SPECS["grad_hist_4_u1"].func if u1 else None, lo=0.5 if u1 else 2.0, hi=20.0 if u1 else 60.0)
     img = synth_image(150 + 13 * seed, 210 + 7 * seed, seed)
     both_kernels(M, img)
+
+
+@pytest.mark.parametrize("T,quiet,u1", [(40, 20, False), (24, 24, False), (12, 12, True), (30, 9, True), (48, 33, False), (7, 7, False)])
+def test_tiles_whose_survivors_overflow_the_capped_queue_go_on_densely(T, quiet, u1):
+    """The workgroup's survivor queue holds 64 * waves + 512 entries, not one per window of the tile: a cascade whose first
+    `quiet` stages never reject (theta = -inf, model.py:253) leaves all 2048 windows of a tile alive behind phase A, so
+    the tile goes on densely, eight stages at a time, until the survivors fit -- or, when the cascade ends first (quiet
+    == T: every window is a detection), emits them from the dense state.  Generic and specialised kernel, rank and uint8
+    tiles, against the oracle."""
+    M = random_model(300 + T + quiet, T, lambda rng: 2, theta_inf=0.0,
+                     func=wb.channels.SPECS["grad_hist_4_u1"].func if u1 else None, lo=0.5 if u1 else 2.0, hi=20.0 if u1 else 60.0)
+    for t in range(quiet):
+        M.theta[t] = float("-inf")
+    for t in range(quiet, T):                                # ... then reject hard, so that the late stages are queue work
+        M.theta[t] = float(np.float32(0.45 * (t - quiet + 1)))
+    img = synth_image(120, 170, 60 + T)
+    ref = both_kernels(M, img)
+    n_windows = ref["alive"][:, 0].sum()
+    assert quiet == 0 or (ref["alive"][:, quiet - 1] == ref["alive"][:, 0]).all()
+    if quiet == T:
+        assert ref["scores"].size == n_windows               # every window survives every stage
 
 
 def test_specialised_kernel_with_special_thresholds_and_leaf_values():

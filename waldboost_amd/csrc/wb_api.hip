@@ -260,11 +260,11 @@ extern "C" int wb_model_create(int n_stages, const int32_t *node_off, const uint
         M->lds_rows = M->tile_rows + m - 1;
         M->lds_stages = (n_stages * WB_STAGE_DWORDS(D) * 4 <= 16 * 1024) ? n_stages : 0;
         // (layout: wb_cascade_tile.h, wb_lds_stab_off; 256 bytes of control words behind the stage mirror)
-        M->lds_bytes = ((C * M->lds_rows * M->lds_pitch * 4 + M->tile_rows * WB_CASC_TC * 8 + n_stages * 4 + 15) & ~15) +
+        M->lds_bytes = ((C * M->lds_rows * M->lds_pitch * 4 + wb_casc_qcap(M->tile_rows, waves) * 8 + n_stages * 4 + 15) & ~15) +
                        M->lds_stages * WB_STAGE_DWORDS(D) * 4 + 256;
-        M->lds_bytes_u8 = ((((C * M->lds_rows * M->lds_pitch + 15) & ~15) + M->tile_rows * WB_CASC_TC * 8 + n_stages * 4 + 15) & ~15) +
+        M->lds_bytes_u8 = ((((C * M->lds_rows * M->lds_pitch + 15) & ~15) + wb_casc_qcap(M->tile_rows, waves) * 8 + n_stages * 4 + 15) & ~15) +
                           M->lds_stages * WB_STAGE_DWORDS(D) * 4 + 256;
-        M->lds_bytes_u16 = ((((C * M->lds_rows * M->lds_pitch * 2 + 15) & ~15) + M->tile_rows * WB_CASC_TC * 8 + n_stages * 4 + 15) & ~15) +
+        M->lds_bytes_u16 = ((((C * M->lds_rows * M->lds_pitch * 2 + 15) & ~15) + wb_casc_qcap(M->tile_rows, waves) * 8 + n_stages * 4 + 15) & ~15) +
                            M->lds_stages * WB_STAGE_DWORDS(D) * 4 + 256;
         if (M->lds_bytes <= budget || rpw <= 1) break;
     }

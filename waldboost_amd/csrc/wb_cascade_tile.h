@@ -48,12 +48,16 @@ static __device__ const int32_t kWbStages[] = {WB_JIT_STAGE_WORDS};
 #ifndef WB_JIT_LDS_STAGES
 #define WB_JIT_LDS_STAGES WB_JIT_T      // stage records mirrored in LDS: all of them, or 0 (a table beyond 16 KiB: long cascades)
 #endif
+#ifndef WB_JIT_WAVES
+#define WB_JIT_WAVES 8
+#endif
 #else
 static __device__ const int32_t kWbStages[1] = {0};
 #define WB_JIT_SEGMENTS(X)
 // (a BAKED build also knows the model's geometry at compile time: stage count, channels, LDS tile rows and pitch)
 #define WB_JIT_T 0
 #define WB_JIT_LDS_STAGES 0
+#define WB_JIT_WAVES 8
 #define WB_JIT_C 0
 #define WB_JIT_ROWS 0
 #define WB_JIT_PITCH 0
@@ -65,8 +69,22 @@ static __device__ const int32_t kWbStages[1] = {0};
 __host__ __device__ constexpr size_t wb_lds_tile_bytes(int eb, int C, int rows, int pitch) {
     return eb ? (((size_t)C * rows * pitch * eb + 15) & ~(size_t)15) : (size_t)C * rows * pitch * 4;
 }
-__host__ __device__ constexpr size_t wb_lds_stab_off(int eb, int C, int rows, int pitch, int TR, int T) {
-    return (wb_lds_tile_bytes(eb, C, rows, pitch) + (size_t)TR * 64 * 8 + (size_t)T * 4 + 15) & ~(size_t)15;
+// Entries of the workgroup's survivor queue (8 bytes each).  Round 4: capped -- 64 * WAVES pooled chunks + 512 -- instead
+// of one entry per window of the tile (2048 for the 32 x 64 tile: 16 KB of the workgroup's 36 KB): a cascade rejects most
+// windows within its first eight stages (431 of 2048 survive them on the benchmark model), and the rare tile that keeps
+// more goes on DENSELY (a lane mask per row, as in phase A) eight stages at a time until its survivors fit.  Under 32 KB
+// of LDS a fifth workgroup fits a CU once waves of the resident four have left (they no longer wait at a final barrier).
+#ifndef WB_CASC_QCAP_DEFINED
+#define WB_CASC_QCAP_DEFINED
+#ifndef WB_CASC_QFULL
+#define WB_CASC_QFULL 0      // 1: the round-3 layout (A/B builds)
+#endif
+__host__ __device__ constexpr int wb_casc_qcap(int TR, int WAVES) {
+    return (WB_CASC_QFULL || TR * 64 < 64 * WAVES + 512) ? TR * 64 : 64 * WAVES + 512;
+}
+#endif
+__host__ __device__ constexpr size_t wb_lds_stab_off(int eb, int C, int rows, int pitch, int TR, int T, int WAVES) {
+    return (wb_lds_tile_bytes(eb, C, rows, pitch) + (size_t)wb_casc_qcap(TR, WAVES) * 8 + (size_t)T * 4 + 15) & ~(size_t)15;
 }
 #define WB_LDS_CTL_BYTES 256
 // experiment switches (A/B builds; the defaults are what measured best)
@@ -78,6 +96,9 @@ __host__ __device__ constexpr size_t wb_lds_stab_off(int eb, int C, int rows, in
 #endif
 #ifndef WB_TAIL_PRIO
 #define WB_TAIL_PRIO 3       // s_setprio of a wave inside the stage-parallel tail (0 = off)
+#endif
+#ifndef WB_CASC_END_BARRIER
+#define WB_CASC_END_BARRIER 0    // 1: a workgroup barrier in front of the statistics flush instead of the arrival counter (A/B builds)
 #endif
 #ifndef WB_SEG_PREFETCH
 #define WB_SEG_PREFETCH 1    // BAKED segments: next group's gathers before this group's rejection tests
@@ -255,7 +276,7 @@ template <int D, int EB, int TR, int T> struct StageAt {
         if constexpr (FAST) {
             // absolute LDS addresses (the tile starts at 0, the stage mirror at a compile-time offset): every constant
             // part of an address is an instruction offset, nothing is added on the vector unit
-            constexpr uint32_t PRED = (uint32_t)wb_lds_stab_off(EB, WB_JIT_C, WB_JIT_ROWS, WB_JIT_PITCH, TR, WB_JIT_T) + (T * SD + 2 * NI) * 4;
+            constexpr uint32_t PRED = (uint32_t)wb_lds_stab_off(EB, WB_JIT_C, WB_JIT_ROWS, WB_JIT_PITCH, TR, WB_JIT_T, WB_JIT_WAVES) + (T * SD + 2 * NI) * 4;
             auto px = [&](int i) {
                 if constexpr (EB == 2)
                     return (uint32_t)*(WbLdsU16)(uint32_t)(base + off(i));
@@ -308,7 +329,8 @@ template <int B, int E, int S, class F> __device__ __forceinline__ void wb_stati
 template <int D, int RPW, int WAVES, int EB, bool BAKED>
 __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32_t *__restrict__ stages) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    static_assert((2 * WAVES + 1) * 4 <= WB_LDS_CTL_BYTES, "control words");
+    static_assert((2 * WAVES + 2) * 4 <= WB_LDS_CTL_BYTES, "control words");
+    static_assert(!BAKED || WAVES == WB_JIT_WAVES, "the prelude's wave count");
     constexpr int NT = WAVES * 64;
     constexpr int TR = RPW * WAVES;
     constexpr int SD = WB_STAGE_DWORDS(D);
@@ -332,21 +354,27 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     constexpr bool U8 = EB != 0;                            // a byte tile (8- or 16-bit elements)
     const size_t tile_bytes = wb_lds_tile_bytes(EB, nC, rows, pitch);
     const int px_stride = EB ? nC * EB : 4;                 // bytes between horizontally adjacent windows' origins
-    uint2 *queue = reinterpret_cast<uint2 *>(smem + tile_bytes) + wave * (RPW * 64);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem + tile_bytes + (size_t)TR * 64 * 8);
+    constexpr int QCAP = wb_casc_qcap(TR, WAVES);           // entries of the survivor queue
+    constexpr bool QPREFIX = QCAP < TR * 64;                // capped: a wave's queue starts at the count of the waves before it
+    uint2 *queue = reinterpret_cast<uint2 *>(smem + tile_bytes) + (QPREFIX ? 0 : wave * (RPW * 64));
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem + tile_bytes + (size_t)QCAP * 8);
 
     const int nr = L.u - a.m > 0 ? L.u - a.m : 0;          // window grid
     const int nc = L.v - a.n > 0 ? L.v - a.n : 0;
     const int r0 = tile_d.ty * TR, c0 = tile_d.tx * WB_CASC_TC;
 
     // LDS mirror of the stage table (when it is small enough): the tail reads one record per lane
-    const size_t stab_off = wb_lds_stab_off(EB, nC, rows, pitch, TR, T);
+    const size_t stab_off = wb_lds_stab_off(EB, nC, rows, pitch, TR, T, WAVES);
     int4 *stab = reinterpret_cast<int4 *>(smem + stab_off);
     // control words behind the mirror: the per-wave counts exchanged at stage 8 and (their own words) at stage 16
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + stab_off + (size_t)(BAKED ? WB_JIT_LDS_STAGES : a.lds_stages) * SD * 4);
     uint32_t *wcnt2 = wcnt + WAVES;
     uint32_t *ticket = wcnt2 + WAVES;           // next unclaimed entry of the workgroup's survivor list (the stage-parallel tail)
-    if (tid == 0) *ticket = 0u;                 // (visible behind the tile load's barrier)
+    uint32_t *arrived = ticket + 1;             // waves that have finished (the last one flushes the tile's statistics)
+    if (tid == 0) {
+        *ticket = 0u;                           // (visible behind the tile load's barrier)
+        *arrived = 0u;
+    }
     // (nothing of this step reads the octaves' min / max keys any more -- the channel kernel has finished: the first
     // workgroup resets them for the next step's octave kernel, which then needs no memset launch in front of it)
     if (blockIdx.x == 0 && blockIdx.y == 0)
@@ -603,16 +631,20 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     //      pooled: by stage 8 a wave keeps only a fraction of its windows (half-empty chunks in
     //      every wave); pooled, they fill whole chunks of 64 for a few waves and the others are
     //      done.  (A second pooling at stage 16 was measured slower.)
+    const uint32_t shard = blockIdx.x % WB_DET_SHARDS;
     int my_cnt = 0;
 #pragma unroll
     for (int j = 0; j < RPW; ++j) my_cnt += __popcll(lm[j]);
     uint32_t total = (uint32_t)my_cnt, before = 0;
     bool pooled = false;
     uint2 *wgq = reinterpret_cast<uint2 *>(smem + tile_bytes);
-    if (T > S0) {
+    int t_done = tA;                                              // stages evaluated so far (densely)
+    // the workgroup's survivors: total, and how many sit in the waves before this one
+    auto recount = [&]() {
         if (lane == 0) wcnt[wave] = (uint32_t)my_cnt;
         __syncthreads();
         total = 0;
+        before = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
             uint32_t c = wcnt[w];
@@ -621,10 +653,79 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
         }
         total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
         before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
-        pooled = total <= 64u * WAVES;                            // same decision in every wave
+    };
+    // stages [t0, t1) on the dense state (hs, lm), records through the scalar cache: the capped queue's fallback.  ONE stage
+    // at a time (a group of G records in scalar registers beside phase A's state spilled scalar registers into the hot
+    // path: +4 % on every tile for the sake of the rare one that comes here)
+    auto dense_more = [&](int t0, int t1) {
+#pragma nounroll
+        for (int t = t0; t < t1; ++t) {
+            Stage<D> st;
+            st.load(stages + (size_t)__builtin_amdgcn_readfirstlane(t) * SD);
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) cnt += __popcll(lm[j]);
+            if (lane == 0 && cnt) atomicAdd(&hist[t], (uint32_t)cnt);
+            const unsigned long long never = never_rejects<BAKED>(st.theta) ? ~0ull : 0ull;
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                hs[j] = hs[j] + st.template eval<EB>(tile, base[j]);
+                lm[j] &= __ballot(hs[j] >= st.theta) | never;
+            }
+        }
+    };
+    if (T > t_done) {
+        recount();
+        if constexpr (QPREFIX) {
+            // more survivors than the queue holds (rare: a tile that a cascade hardly thins out): on densely, eight stages
+            // at a time, until they fit -- or the cascade ends
+            while (total > (uint32_t)QCAP) {
+                const int t1 = t_done + S0 < T ? t_done + S0 : T;
+                dense_more(t_done, t1);
+                t_done = t1;
+                my_cnt = 0;
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) my_cnt += __popcll(lm[j]);
+                __syncthreads();                                  // every wave has read wcnt
+                if (t_done >= T) break;
+                recount();
+            }
+        }
+        pooled = t_done < T && total <= 64u * WAVES;              // same decision in every wave
     }
-    {
-        uint2 *dstq = pooled ? wgq + before : queue;
+    int n_q = my_cnt;
+    if (QPREFIX && t_done >= T) {
+        // every stage has been evaluated on the dense state (a cascade of at most S0 stages, or a tile whose survivors never
+        // fitted the queue): the windows still alive are detections -- one returning atomic per wave, records straight out
+        if (my_cnt > 0) {
+            uint32_t s0 = 0;
+            if (lane == 0) s0 = atomicAdd(a.det_count + shard, (uint32_t)my_cnt);
+            s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0);
+            WbDet *dst = a.det + (size_t)shard * a.det_cap;
+            uint32_t n_loc = 0;
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const unsigned long long mask = lm[j];
+                if ((mask >> lane) & 1ull) {
+                    const uint32_t at = s0 + n_loc + (uint32_t)lane_rank(mask);
+                    if (at < a.det_cap) {
+                        WbDet d;
+                        d.image = b;
+                        d.level = tile_d.level;
+                        d.r = (uint16_t)(r0 + wr + j);
+                        d.c = (uint16_t)(c0 + lane);
+                        d.score = hs[j];
+                        dst[at] = d;
+                    }
+                }
+                n_loc += (uint32_t)__popcll(mask);
+            }
+        }
+        n_q = 0;
+    } else {
+        // (capped queue: every wave's entries start at the count of the waves before it, pooled or not)
+        uint2 *dstq = (pooled || QPREFIX) ? wgq + before : queue;
+        if (QPREFIX && !pooled) queue = wgq + before;
         int n_loc = 0;
 #pragma unroll
         for (int j = 0; j < RPW; ++j) {
@@ -636,11 +737,10 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
             n_loc += cnt;
         }
     }
-    int n_q = my_cnt;
     bool scatter = false;
     const uint2 *dyn_list = nullptr;                              // scatter: the workgroup's shared survivor list ...
     int dyn_total = 0;                                            // ... and its length
-    if (T > S0) {
+    if (T > t_done) {
         __syncthreads();                                          // pooled entries visible; wcnt free again
         if (pooled) {
             // Few survivors in the whole tile (the usual case for a rejecting cascade: a few dozen of 2048):
@@ -665,7 +765,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     WB_STAMP(3);
 
     // ---- phase B: dense re-packed survivors, stage segments [S0,2S0), [2S0,4S0), ...
-    int t_begin = tA;
+    int t_begin = t_done;
     // wave-synchronous segments from t_begin up to (at most) t_stop, compacting after each
     auto run_segments = [&](int t_stop) {
         while (t_begin < t_stop && n_q > 0) {
@@ -793,7 +893,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
         // stages to go: count them workgroup-wide once more and, if they are few, deal them out to all waves for
         // the stage-parallel evaluator (as above after phase A).
         constexpr int S1 = 2 * S0;
-        if (RPW >= 2 && pooled && T > S1) {
+        if (RPW >= 2 && pooled && T > S1 && t_begin == S0) {
             run_segments(S1);
             if (lane == 0) wcnt2[wave] = (uint32_t)n_q;
             __syncthreads();
@@ -806,7 +906,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
             }
             total2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)total2);
             before2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)before2);
-            const uint32_t room = 64u * WAVES * (RPW - 1);             // queue entries behind the pooled chunks
+            const uint32_t room = (uint32_t)QCAP - 64u * WAVES;         // queue entries behind the pooled chunks
             if (total2 <= ((uint32_t)a.spar_wg < room ? (uint32_t)a.spar_wg : room)) {   // same decision in every wave
                 uint2 *list2 = wgq + 64 * WAVES;                      // (the pooled chunks occupy the first 64 * WAVES entries)
                 for (int i = lane; i < n_q; i += 64) list2[before2 + i] = queue[i];
@@ -824,7 +924,6 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     if (a.dbg & 16) return;
 
     // ---- stage-parallel tail: lane i evaluates stage rs + i of a window (two windows side by side)
-    const uint32_t shard = blockIdx.x % WB_DET_SHARDS;
     // this lane's record for stage rs + lane (the LDS mirror, or HBM when the table is too large for it)
     auto lane_stage = [&](int rs) {
         Stage<D> st;
@@ -1013,18 +1112,6 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     //      nobody waits for another wave's atomic.  (The order of the records inside a shard was never defined.)
     uint32_t slot0 = 0;
     if (n_q > 0 && lane == 0) slot0 = atomicAdd(a.det_count + shard, (uint32_t)n_q);
-    __syncthreads();                                          // every wave's per-stage counts are in hist
-    // per-stage alive counts of this tile -> alive[image][level][stage]: one fire-and-forget atomic per stage the
-    // tile reached, once per workgroup (the workgroup's waves have summed in LDS; an atomic per wave and stage made
-    // every wave of every tile queue up behind the others')
-    if (a.alive) {
-        uint32_t *al = a.alive + ((int64_t)b * a.n_levels + tile_d.level) * a.T;
-        for (int t = tid; t < T; t += NT) {
-            const uint32_t c = hist[t];
-            if (c) atomicAdd(al + t, c);
-        }
-    }
-    WB_STAMP(6);
     if (n_q > 0) {
         const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
         WbDet *dst = a.det + (size_t)shard * a.det_cap;
@@ -1039,6 +1126,38 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
                 d.score = __uint_as_float(e.y);
                 dst[o + i] = d;
             }
+        }
+    }
+    WB_STAMP(6);
+    // per-stage alive counts of this tile -> alive[image][level][stage]: one fire-and-forget atomic per stage the
+    // tile reached, once per workgroup (the workgroup's waves have summed in LDS; an atomic per wave and stage made
+    // every wave of every tile queue up behind the others').  Round 4: no barrier in front of it -- a wave that is done
+    // says so (one LDS atomic; its additions to hist are in before it counts) and
+    // LEAVES; the last one to arrive flushes the sums.  The waves that carried nothing through the late stages -- most of
+    // them -- used to wait here for a fifth of the workgroup's lifetime holding their wave slots.
+#if WB_CASC_END_BARRIER
+    __syncthreads();                                          // (A/B build: the round-3 ending -- every wave waits, all flush)
+    if (a.alive) {
+        uint32_t *al = a.alive + ((int64_t)b * a.n_levels + tile_d.level) * a.T;
+        for (int t = tid; t < T; t += NT) {
+            const uint32_t c = hist[t];
+            if (c) atomicAdd(al + t, c);
+        }
+    }
+    return;
+#endif
+    uint32_t earlier = 0;
+    // (LDS serves a wave's operations in order: this wave's additions to hist are performed before its arrival is; the
+    // compiler must not move them across it either -- hence the two barriers around a plain atomic)
+    asm volatile("" ::: "memory");
+    if (lane == 0) earlier = atomicAdd(arrived, 1u);
+    asm volatile("" ::: "memory");
+    earlier = (uint32_t)__builtin_amdgcn_readfirstlane((int)earlier);
+    if (earlier == (uint32_t)WAVES - 1u && a.alive) {
+        uint32_t *al = a.alive + ((int64_t)b * a.n_levels + tile_d.level) * a.T;
+        for (int t = lane; t < T; t += 64) {
+            const uint32_t c = hist[t];
+            if (c) atomicAdd(al + t, c);
         }
     }
     WB_STAMP(7);

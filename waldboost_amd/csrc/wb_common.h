@@ -84,6 +84,20 @@ __device__ inline double wb_round_f16(double x) {
 #define WB_BIN16_CELLS 512
 #define WB_BIN16_LUT_BYTES (4 * WB_BIN16_SLOTS * 4 + 4 * WB_BIN16_CELLS * 2)   // float S[4][1024], then uint16 base[4][512]
 
+// entries of the cascade workgroup's survivor queue (wb_cascade_tile.h: the same definition, for the hiprtc build)
+#ifndef WB_CASC_QCAP_DEFINED
+#define WB_CASC_QCAP_DEFINED
+#ifndef WB_CASC_QFULL
+#define WB_CASC_QFULL 0
+#endif
+__host__ __device__ constexpr int wb_casc_qcap(int TR, int WAVES) {
+    return (WB_CASC_QFULL || TR * 64 < 64 * WAVES + 512) ? TR * 64 : 64 * WAVES + 512;
+}
+#endif
+#ifndef WB_CASC_END_BARRIER
+#define WB_CASC_END_BARRIER 0
+#endif
+
 // The canonical stage record the cascade kernels read with scalar loads:
 //   int   off[NI]   LDS byte offset of each internal node's feature (BFS order)
 //   float thr[NI]

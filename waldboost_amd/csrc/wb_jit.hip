@@ -75,6 +75,8 @@ std::string make_source(const int32_t *words, size_t n_words, int T, int D, int 
     }
     s += "\n#define WB_JIT_SEGMENTS(X)" + segment_list(T) + "\n";
     s += "#define WB_JIT_LDS_STAGES " + std::to_string(lds_stages < 0 ? T : lds_stages) + "\n";
+    s += "#define WB_JIT_WAVES " + std::to_string(waves) + "\n#define WB_CASC_QFULL " + std::to_string((int)WB_CASC_QFULL) + "\n#define WB_CASC_END_BARRIER " +
+         std::to_string((int)WB_CASC_END_BARRIER) + "\n";
     s += "#define WB_JIT_T " + std::to_string(T) + "\n#define WB_JIT_C " + std::to_string(C) + "\n#define WB_JIT_ROWS " +
          std::to_string(rows) + "\n#define WB_JIT_PITCH " + std::to_string(pitch) + "\n";
     s += "#include \"wb_cascade_tile.h\"\n";
