@@ -145,3 +145,25 @@ def test_random_configurations_with_the_cascade_specialised_on_its_first_scan(se
     monkeypatch.setattr(E, "_JIT_AFTER", 1)
     monkeypatch.setattr(E, "_JIT_AUTO", True)
     F.test_random_configuration(seed)
+
+
+def test_the_disk_cache_of_specialised_kernels_is_bounded_and_checks_what_it_loads(tmp_path, monkeypatch):
+    """A loop that changes its model every iteration must not leave one code object per model content behind for ever:
+    the cache directory is pruned, oldest first, to WB_JIT_CACHE_MAX files; a cached file that is not an ELF image is
+    compiled again instead of being handed to the module loader."""
+    monkeypatch.setenv("WB_JIT_CACHE", str(tmp_path))
+    monkeypatch.setenv("WB_JIT_CACHE_MAX", "2")
+    img = synth_image(120, 160, 3)
+    for k in range(4):
+        M = random_model(900 + k, 10, lambda rng: 2)
+        assert M.device_cascade().specialize()
+        assert_same(M.detect_raw(img), oracle_detect(M, img))
+        assert len([f for f in os.listdir(tmp_path) if f.endswith(".co")]) <= 2
+    # a damaged entry: the same model in a fresh process state would load it -- here: overwrite every cached file, build
+    # a model whose kernel is not loaded yet, and see it compile instead of failing
+    for f in os.listdir(tmp_path):
+        with open(tmp_path / f, "wb") as fh:
+            fh.write(b"not a code object")
+    M = random_model(950, 10, lambda rng: 2)
+    assert M.device_cascade().specialize()
+    assert_same(M.detect_raw(img), oracle_detect(M, img))

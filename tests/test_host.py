@@ -64,7 +64,8 @@ def test_channels_tile_query_and_argument_errors_without_gpu():
     assert lib.wb_channels_tile(nat.WB_CHN_GRAD_HIST, 2, C.byref(tu), C.byref(tv)) == 0 and (tu.value, tv.value) == (16, 64)
     assert lib.wb_channels_tile(nat.WB_CHN_GRAD_HIST_4_U1, 2, C.byref(tu), C.byref(tv)) == 0 and (tu.value, tv.value) == (16, 64)
     assert lib.wb_channels_tile(nat.WB_CHN_GRAD_HIST, 1, C.byref(tu), C.byref(tv)) == 0 and (tu.value, tv.value) == (16, 64)
-    assert lib.wb_channels_tile(nat.WB_CHN_GRAD_HIST, 4, C.byref(tu), C.byref(tv)) == 0 and (tu.value, tv.value) == (8, 32)
+    assert lib.wb_channels_tile(nat.WB_CHN_GRAD_HIST, 4, C.byref(tu), C.byref(tv)) == 0 and (tu.value, tv.value) == (8, 30)
+    assert lib.wb_channels_tile(nat.WB_CHN_GRAD_HIST_4_U1, 4, C.byref(tu), C.byref(tv)) == 0 and (tu.value, tv.value) == (8, 32)
     assert lib.wb_channels_tile(nat.WB_CHN_GRAD_HIST, 3, C.byref(tu), C.byref(tv)) == nat.WB_ERR_UNSUPPORTED
     assert b"shrink=3" in lib.wb_last_error()
     # null pointers are rejected before any HIP call

@@ -75,6 +75,12 @@ __device__ unsigned long long g_chan_stamps[WB_CSTAMP_WGS * WB_CSTAMP_SLOTS];
 #ifndef WB_CHAN_S4_WAVES
 #define WB_CHAN_S4_WAVES (WB_CHAN_S4_BYTES ? 5 : 3)
 #endif
+// shrink 4, grad_hist: output tile 8 x WB_CHAN_S4_TV.  30 (round 4): the shrunk tile with its smooth halo is then 10 x 32 = 320
+// pixels = five full waves of step 2 (8 x 32 gave 340: a sixth wave ran for twenty lanes), and the resized tile 130 columns =
+// two per lane + 2 left over (138: + 10)
+#ifndef WB_CHAN_S4_TV
+#define WB_CHAN_S4_TV 30
+#endif
 typedef WbTap Tap;   // one axis of the bilinear resample (scipy NI_ZoomShift, order 1), host-built table
 
 // a double held by lane `k` (wave-uniform k), to every lane
@@ -1001,15 +1007,17 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ?
     // ---- step 3: 3x3 binomial smooth (fp64 sum in source order, /16, one rounding), border = 0.
     //      Each thread owns RPT vertically adjacent outputs of one column, so every shrunk value
     //      it needs is read and widened to fp64 once for up to three output rows.
-    constexpr int RPT = TU * TV / NT;
-    static_assert(TU * TV % NT == 0 && NT % TV == 0, "tile must split into whole thread strips");
+    // (tiles that do not split into whole strips -- 8 x 30 on 256 threads: one output per thread, the last threads idle)
+    constexpr bool WHOLE = TU * TV % NT == 0 && NT % TV == 0;
+    constexpr int RPT = WHOLE ? TU * TV / NT : 1;
+    static_assert(WHOLE || TU * TV <= NT, "one output per thread");
     float *out = reinterpret_cast<float *>(a.chn) + (int64_t)b * a.chn_stride + L.chn_off;
     const int j = tid % TV, i0 = (tid / TV) * RPT;
     const int sv = v0 + j;
     float o[RPT][4];
     // (64-wide tiles: a wave owns whole output rows, so on a bottom-edge tile the waves whose rows lie past the level
     // skip the smooth and the ranks -- wave-uniform; they still meet the barrier below)
-    const bool live = TV != 64 || u0 + __builtin_amdgcn_readfirstlane(i0) < L.u;
+    const bool live = WHOLE ? (TV != 64 || u0 + __builtin_amdgcn_readfirstlane(i0) < L.u) : i0 < TU;
 #pragma unroll
     for (int y = 0; y < RPT; ++y) o[y][0] = o[y][1] = o[y][2] = o[y][3] = 0.0f;
     if (!live) {
@@ -1068,7 +1076,7 @@ __global__ __launch_bounds__(NT, sizeof(T) == 8 ? 1 : S == 4 ? (sizeof(T) == 1 ?
 #pragma unroll
     for (int y = 0; y < RPT; ++y) {
         const int su = u0 + i0 + y;
-        if (su >= L.u || sv >= L.v || (a.dbg & 4)) continue;
+        if ((!WHOLE && !live) || su >= L.u || sv >= L.v || (a.dbg & 4)) continue;
         if (SMOOTH && (su == 0 || sv == 0 || su == L.u - 1 || sv == L.v - 1)) o[y][0] = o[y][1] = o[y][2] = o[y][3] = 0.0f;
         // one float4 per pixel ([u][v][4]): 64 lanes store 1 KiB contiguous
         if (a.chn) {
@@ -1336,7 +1344,7 @@ int launch_dtype(hipStream_t st, dim3 grid, const ChanArgs &a, int shrink, bool 
             else
                 launch_variant<T, 2, 16, 64, FAST>(st, grid, a, smooth);
             break;
-        case 4: launch_variant<T, 4, 8, 32, FAST>(st, grid, a, smooth); break;
+        case 4: launch_variant<T, 4, 8, WB_CHAN_S4_TV, FAST>(st, grid, a, smooth); break;
         default:
             wb_set_error("wb_channels_launch: shrink=%d unsupported (1, 2; 4 as an extension)", shrink);
             return WB_ERR_UNSUPPORTED;
@@ -1746,7 +1754,7 @@ extern "C" int wb_channels_tile(int channel_func, int shrink, int *tile_u, int *
         *tile_v = 64;
     } else if (shrink == 4) {
         *tile_u = 8;
-        *tile_v = 32;
+        *tile_v = channel_func == WB_CHN_GRAD_HIST ? WB_CHAN_S4_TV : 32;
     } else {
         wb_set_error("wb_channels_tile: shrink=%d unsupported", shrink);
         return WB_ERR_UNSUPPORTED;
@@ -1791,13 +1799,14 @@ void fill_patches(const WbLevel *levels, const WbTile *tiles, int n_tiles, WbTil
 }
 template <bool FULL_ROWS>
 int fill_patches_for(int shrink, bool smooth, bool big, const WbLevel *levels, const WbTile *tiles, int n_tiles, WbTilePatch *out) {
+    constexpr int TV4 = FULL_ROWS ? 32 : WB_CHAN_S4_TV;      // (the uint8 channel functions keep the 8 x 32 tile)
 #define WB_FP(S, TU, TV)                                                                  \
     if (smooth) fill_patches<TileGeom<S, TU, TV, true>, FULL_ROWS>(levels, tiles, n_tiles, out); \
     else fill_patches<TileGeom<S, TU, TV, false>, FULL_ROWS>(levels, tiles, n_tiles, out);
     switch (shrink) {
         case 1: WB_FP(1, 16, 64) return WB_OK;
         case 2: if (big) { WB_FP(2, 32, 64) } else { WB_FP(2, 16, 64) } return WB_OK;
-        case 4: WB_FP(4, 8, 32) return WB_OK;
+        case 4: WB_FP(4, 8, TV4) return WB_OK;
     }
 #undef WB_FP
     wb_set_error("wb_channels_tile_patches: shrink=%d unsupported (1, 2; 4 as an extension)", shrink);

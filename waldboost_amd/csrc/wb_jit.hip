@@ -11,8 +11,11 @@
 #include <hip/hiprtc.h>
 #include <stdlib.h>
 #include <string.h>
+#include <dirent.h>
 #include <sys/stat.h>
 #include <unistd.h>
+
+#include <algorithm>
 
 #include <map>
 #include <mutex>
@@ -106,11 +109,40 @@ bool read_file(const std::string &path, std::vector<char> &out) {
     return ok;
 }
 
+// The disk cache is bounded: before a new code object is written, the oldest ones (by modification time) go until at most
+// WB_JIT_CACHE_MAX - 1 (default 256) are left -- a loop that changes its model every iteration (training with the uint8
+// channel functions, threshold sweeps) otherwise leaves one file per model content behind, for ever.
+void prune_cache(const std::string &dir) {
+    const int cap = getenv("WB_JIT_CACHE_MAX") ? atoi(getenv("WB_JIT_CACHE_MAX")) : 256;
+    DIR *d = opendir(dir.c_str());
+    if (!d) return;
+    std::vector<std::pair<time_t, std::string>> files;
+    while (struct dirent *e = readdir(d)) {
+        const std::string n = e->d_name;
+        if (n.size() != 19 || n.compare(16, 3, ".co") != 0) continue;          // (only what this cache wrote: <16 hex digits>.co)
+        struct stat st;
+        if (stat((dir + "/" + n).c_str(), &st) == 0) files.emplace_back(st.st_mtime, n);
+    }
+    closedir(d);
+    if ((int)files.size() < cap) return;
+    std::sort(files.begin(), files.end());
+    for (size_t i = 0; i + (size_t)(cap > 0 ? cap - 1 : 0) < files.size(); ++i) (void)unlink((dir + "/" + files[i].second).c_str());
+}
+
+// a cached file is only handed to the module loader if it looks like what compile() produces: an ELF image of plausible
+// size, owned by this user (WB_JIT_CACHE may point at a shared directory)
+bool plausible_code_object(const std::string &path, const std::vector<char> &code) {
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0 || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) return false;
+    return code.size() > 64 && code[0] == 0x7f && code[1] == 'E' && code[2] == 'L' && code[3] == 'F';
+}
+
 void write_file_atomic(const std::string &dir, const std::string &path, const std::vector<char> &data) {
     if (dir.empty()) return;
     const size_t slash = dir.rfind('/');
     if (slash != std::string::npos && slash > 0) (void)mkdir(dir.substr(0, slash).c_str(), 0755);
     (void)mkdir(dir.c_str(), 0755);
+    prune_cache(dir);
     const std::string tmp = path + "." + std::to_string((long)getpid()) + ".tmp";
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return;
@@ -207,7 +239,7 @@ int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int 
     snprintf(name, sizeof(name), "%016llx.co", (unsigned long long)h);
     const std::string dir = cache_dir(), path = dir.empty() ? std::string() : dir + "/" + name;
     std::vector<char> code;
-    if (path.empty() || !read_file(path, code)) {
+    if (path.empty() || !read_file(path, code) || !plausible_code_object(path, code)) {
         std::string log;
         const int rc = compile(src, prop.gcnArchName, code, log);
         if (rc != WB_OK) {
