@@ -405,6 +405,14 @@ __host__ __device__ __forceinline__ bool tile_patch_extent(const WbLevel &L, int
 // whole dwords: a quarter of the LDS, for the price of one conversion per store here and one per read in the caller.
 template <typename RT, int RW> struct RPitch { static constexpr int value = sizeof(RT) == 1 ? ((RW + 3) & ~3) : RW; };
 
+// rows of a wave's strip of the resample: an even share of the rh tile rows, rounded up to whole passes of WB_CHAN_RB rows --
+// 42 rows on four waves are then 12 + 12 + 12 + 6 (21 passes) instead of 11 + 11 + 11 + 9 (23: every wave ended on a pass of
+// one row)
+#ifndef WB_CHAN_RB
+#define WB_CHAN_RB 2
+#endif
+__host__ __device__ constexpr int wb_strip_rows(int rh, int nw) { return WB_CHAN_RB * ((rh + nw * WB_CHAN_RB - 1) / (nw * WB_CHAN_RB)); }
+
 template <typename T, typename G, bool REFLECT = false, typename RT = float>
 __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &L, const T *src, const double mn,
                                               const double mx, const int ry0, const int rx0, const int rh, RT *R,
@@ -503,8 +511,8 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             tcs[c] = ctap[x];
         }
         {
-            static_assert((RH + NW - 1) / NW <= 64, "one lane per row of the strip");
-            const int RS = (rh + NW - 1) / NW;                  // rows of a wave's strip (see the row loop)
+            static_assert(wb_strip_rows(RH, NW) <= 64, "one lane per row of the strip");
+            const int RS = wb_strip_rows(rh, NW);               // rows of a wave's strip (see the row loop)
             const int kl = wave * RS + lane;
             const int ly = tile_coord<REFLECT>(ry0 + (kl < rh ? kl : rh - 1), L.nh);
             trl = rtap[ly];
@@ -552,7 +560,7 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             // -- on gfx950 an fp32 add / multiply / fmac whose operands are all vector registers issues in 2 cycles,
             // with a scalar-register operand in 4 (tools/valu_class_probe.hip), and a v_readlane costs 4 as well
             {
-                const int RS = (rh + NW - 1) / NW;
+                const int RS = wb_strip_rows(rh, NW);
                 const int kl = wave * RS + lane;
                 if (lane < RS && kl < rh) rowtab[kl] = make_float4(__int_as_float((trl.i0 - r_lo) * PPITCH), (float)trl.w0, (float)trl.w1, 0.0f);
             }
@@ -585,9 +593,9 @@ __device__ __forceinline__ void resample_tile(const ChanArgs &a, const WbLevel &
             // (next pass's row entries, the previous row's interpolation and tap bytes) --, a pixel's four tap bytes hang
             // off ONE address register (volatile loads, see lds_byte_vol), the tap bytes are not kept for the redo (it reads
             // them again: a redo is rare per pixel), and nothing is left for the SLP vectoriser to pair.
-            constexpr int RB = 2;
-            constexpr int RSMAX = (RH + NW - 1) / NW, NPASS = (RSMAX + RB - 1) / RB;
-            const int RS = (rh + NW - 1) / NW;
+            constexpr int RB = WB_CHAN_RB;
+            constexpr int RSMAX = wb_strip_rows(RH, NW), NPASS = RSMAX / RB;
+            const int RS = wb_strip_rows(rh, NW);
             const int k_lo = wave * RS, k_hi = k_lo + RS < rh ? k_lo + RS : rh;
             float hprev[NCS];                     // horizontal interpolation of the patch row at byte offset o_prev
             int o_prev = -1;
