@@ -17,8 +17,8 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-@pytest.mark.parametrize("seed", range(64))
-def test_random_configuration(seed):
+def random_configuration(seed):
+    """-> (model, image) of the seed's random configuration."""
     rng = np.random.default_rng(1000 + seed)
     key, C, _, (lo, hi) = FUNCS[seed % 4]
     func = wb.channels.SPECS[key].func
@@ -41,10 +41,35 @@ def test_random_configuration(seed):
         f, th, l, r, p = random_tree_arrays(rng, shape, depth, lo, hi, unbalanced=(depth == 2 and rng.random() < 0.3))
         acc += step
         M.append(wb.DTree(f, th, l, r, p), float("-inf") if rng.random() < 0.2 else float(np.float32(acc)))
+    return M, img
+
+
+def check_against_oracle(M, img, counters=True):
     ref = oracle_detect(M, img)
     res = M.detect_raw(img)
-    assert np.array_equal(res["alive"], ref["alive"]), (key, img_dtype, H, W, opts, shape, T)
+    assert np.array_equal(res["alive"], ref["alive"]), (img.dtype, img.shape, M.channel_opts, M.shape, len(M))
     assert np.array_equal(res["level"], ref["level"]) and np.array_equal(res["r"], ref["r"]) and np.array_equal(res["c"], ref["c"])
     assert np.array_equal(bits(res["scores"]), bits(ref["scores"]))
     assert np.array_equal(bits(res["boxes"]), bits(ref["boxes"]))
-    assert M.n_loc == ref["n_loc"] and M.n_weak == ref["n_weak"]
+    if counters:                                  # (the model's counters add up over its scans, as the reference's do)
+        assert M.n_loc == ref["n_loc"] and M.n_weak == ref["n_weak"]
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_random_configuration(seed):
+    check_against_oracle(*random_configuration(seed))
+
+
+# Seeds 558, 569 and 644 are the three of seeds 464..700 that failed in round 4 when the cascade kernel was specialised
+# before the first scan: depth-3 trees under a permissive cascade (10k-89k detections, tiles with more than 1024
+# survivors after eight stages).  Their specialised kernels, forced into 64 registers, had spilled two registers to scratch
+# memory, and the builds with scratch wrote a few wrong records per such tile (a specialised kernel is now built without
+# scratch or not at all: csrc/wb_jit.hip build_without_scratch).  Three passes each: the damage came and went.
+@pytest.mark.parametrize("seed", [558, 569, 644, 5, 18, 41])
+def test_random_configuration_through_the_specialised_kernel(seed):
+    M, img = random_configuration(seed)
+    dm = M.device_cascade()
+    assert dm.specialize(), "the specialised kernel was refused"
+    assert dm.specialized()
+    for k in range(3):
+        check_against_oracle(M, img, counters=k == 0)

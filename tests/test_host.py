@@ -41,14 +41,54 @@ def test_specialised_cascade_kernel_source_compiles_for_gfx950_without_a_gpu(dep
     assert n.value > 4096
 
 
-@pytest.mark.parametrize("depth,stages,eb", [(2, 128, 2), (3, 40, 2), (2, 1024, 1), (2, 1024, 2)])
+@pytest.mark.parametrize("depth,stages,eb", [(2, 128, 2), (3, 40, 2), (2, 1024, 1), (2, 1024, 2), (3, 200, 1)])
 def test_specialised_kernel_source_compiles_for_16_bit_tiles_and_long_cascades(depth, stages, eb):
     """The same generator for tiles of two-byte elements (WB_DTYPE_RANK16) and for cascades whose stage table is not
-    mirrored in LDS (1024 stages: only the first segments are unrolled, the rest runs the kernel's generic loop)."""
+    mirrored in LDS (1024 stages: only the first segments are unrolled, the rest runs the kernel's generic loop).
+    The check fails for a build that asks for scratch memory (wb_jit.hip build_without_scratch): depth-3 trees and
+    1024 stages are the shapes whose builds did, in round 4."""
     lib = nat.load()
     n = C.c_int64()
     nat.check(lib.wb_jit_compile_check2(depth, stages, eb, b"gfx950", C.byref(n)), "wb_jit_compile_check2")
     assert n.value > 4096
+
+
+def _kernel_scratch_sizes(blob):
+    """{kernel name: .private_segment_fixed_size} from the msgpack metadata notes of the code objects in `blob`."""
+    def uint_at(v):
+        return (v[0] if v[0] <= 0x7F else int.from_bytes(v[1:2], "big") if v[0] == 0xCC else
+                int.from_bytes(v[1:3], "big") if v[0] == 0xCD else int.from_bytes(v[1:5], "big") if v[0] == 0xCE else -1)
+
+    def str_at(k):
+        h = blob[k]
+        if h == 0xD9:
+            return blob[k + 2:k + 2 + blob[k + 1]]
+        if h == 0xDA:
+            return blob[k + 3:k + 3 + int.from_bytes(blob[k + 1:k + 3], "big")]
+        return blob[k + 1:k + 1 + (h & 0x1F)]
+
+    key, out = b".private_segment_fixed_size", {}
+    at = blob.find(key)
+    while at >= 0:
+        name = str_at(blob.rfind(b".name", 0, at) + 5).decode()
+        out[name] = uint_at(blob[at + len(key):at + len(key) + 5])
+        at = blob.find(key, at + 1)
+    return out
+
+
+def test_no_cascade_kernel_of_the_library_uses_scratch_memory():
+    """The cascade kernels keep their state in registers and LDS: `.private_segment_fixed_size` is 0 in the metadata of
+    every one of them (their waves leave one by one; a specialised build WITH scratch memory wrote wrong records under
+    that in round 4 -- see wb_jit.hip build_without_scratch, which refuses such a build).  The only kernels of the library
+    with scratch are four instances of the channel kernel that spill two or three registers outside their loops."""
+    nat.load()
+    sizes = _kernel_scratch_sizes(open(nat.LIB_PATH, "rb").read())
+    casc = {k: v for k, v in sizes.items() if "cascade" in k}
+    assert len(casc) > 50, len(casc)               # (every template instance of the tile kernel)
+    assert set(casc.values()) == {0}, {k: v for k, v in casc.items() if v}
+    with_scratch = {k: v for k, v in sizes.items() if v != 0}
+    assert all("channels_kernelI" in k and 0 < v <= 16 for k, v in with_scratch.items()), with_scratch
+    assert len(with_scratch) <= 4, with_scratch
 
 
 def test_abi_struct_sizes_match_header():

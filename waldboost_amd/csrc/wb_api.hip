@@ -12,7 +12,7 @@
 int wb_cascade_prepare(int depth, int rpw, int waves);  // wb_cascade.hip
 int wb_cascade_group(int depth);                        // stages evaluated per group
 int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch, int eb,
-               int lds_stages, void **func_out);   // wb_jit.hip
+               int lds_stages, int compiler, void **func_out);   // wb_jit.hip
 
 static thread_local char g_err[512] = "";
 
@@ -487,6 +487,139 @@ extern "C" int wb_model_info(const WbModel *model, WbModelInfo *info) {
 
 // The model-specialised kernel for one kind of byte tile (wb_jit.hip): compiled with hiprtc on first use (a couple of
 // seconds), then taken from the process / disk cache.  wb_cascade_launch uses it from then on for that channel dtype.
+// A specialised kernel is run-time compiled code for ONE model: before it is trusted it scans a synthetic two-level
+// pyramid of byte tiles several times and must give, every time, exactly what the generic kernel of the library gives on
+// the same bytes: per-stage alive counts and the detection records (window, score bits).  The levels hold tiles of every
+// kind the kernel distinguishes -- regions of different byte statistics, so that under most cascades some tiles keep more
+// windows than the capped queue holds, some a few hundred, some a handful --, a ragged right and bottom edge, and a level
+// of a single partial tile.  Round 4 (profiles/r04/jit_selftest.txt): the code one hiprtc produced for some cascades of
+// depth-3 trees gave wrong records on nine scans of ten; nothing in the source explains it (the toolkit's own compiler, or
+// any of four unrelated build switches, gave bit-exact kernels).  A kernel that fails is not used: WB_ERR_UNSUPPORTED,
+// the model stays on the generic kernel.  WB_JIT_SELFTEST=<passes> (default 6; 0 = skip the test).
+static int jit_selftest(WbModel *model, int chn_dtype, void **slot) {
+    static const int passes = getenv("WB_JIT_SELFTEST") ? atoi(getenv("WB_JIT_SELFTEST")) : 6;
+    if (passes <= 0) return WB_OK;
+    const int eb = chn_dtype == WB_DTYPE_RANK16 ? 2 : 1, C = model->C, m = model->m, n = model->n, T = model->n_stages, TR = model->tile_rows;
+    struct Lv { int gh, gw; } lv[2] = {{2 * TR + TR / 2 + 1, 64 + 37}, {TR / 2 - 3 > 0 ? TR / 2 - 3 : 1, 24}};
+    std::vector<WbLevel> levels(2);
+    std::vector<WbTile> tiles;
+    int64_t elems = 0, windows = 0;
+    for (int l = 0; l < 2; ++l) {
+        memset(&levels[l], 0, sizeof(WbLevel));
+        levels[l].u = lv[l].gh + m;
+        levels[l].v = lv[l].gw + n;
+        levels[l].chn_off = elems;
+        elems += (int64_t)levels[l].u * levels[l].v * C;
+        windows += (int64_t)lv[l].gh * lv[l].gw;
+        for (int ty = 0; ty * TR < lv[l].gh; ++ty)
+            for (int tx = 0; tx * 64 < lv[l].gw; ++tx) tiles.push_back(WbTile{l, (uint16_t)ty, (uint16_t)tx});
+    }
+    // bytes: four kinds of 16 x 16 regions (the whole range, dark, middle, bright), LCG noise inside
+    std::vector<uint8_t> host((size_t)elems * eb + 16, 0);
+    uint32_t x = 2463534242u;
+    for (int l = 0; l < 2; ++l)
+        for (int r = 0; r < levels[l].u; ++r)
+            for (int c = 0; c < levels[l].v; ++c)
+                for (int ch = 0; ch < C; ++ch) {
+                    x = x * 1664525u + 1013904223u;
+                    const int kind = ((r >> 4) + 2 * (c >> 4) + l) & 3;
+                    const uint32_t lo = kind == 0 ? 0u : kind == 1 ? 0u : kind == 2 ? 100u : 200u, span = kind == 0 ? 256u : kind == 1 ? 32u : kind == 2 ? 60u : 56u;
+                    const uint32_t v = (lo + (x >> 16) % span) * (eb == 2 ? 3u : 1u);
+                    const size_t at = (size_t)levels[l].chn_off + ((size_t)r * levels[l].v + c) * C + ch;
+                    if (eb == 1) host[at] = (uint8_t)v;
+                    else memcpy(&host[at * 2], &v, 2);
+                }
+    const uint32_t cap = (uint32_t)windows;                  // per shard: every window of the pyramid may survive in one
+    uint8_t *chn = nullptr;
+    WbLevel *d_levels = nullptr;
+    WbTile *d_tiles = nullptr;
+    WbDet *det = nullptr;
+    uint32_t *ctr = nullptr;                                 // [WB_DET_SHARDS] counts, then alive [2][T]
+    const size_t ctr_words = WB_DET_SHARDS + 2 * (size_t)T;
+    hipStream_t st = nullptr;
+    auto cleanup = [&]() {
+        if (st) (void)hipStreamDestroy(st);
+        (void)hipFree(chn); (void)hipFree(d_levels); (void)hipFree(d_tiles); (void)hipFree(det); (void)hipFree(ctr);
+    };
+#define WB_ST_CHECK(expr)                                                                            \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            wb_set_error("wb_model_specialize (self-test): %s: %s", #expr, hipGetErrorString(e_));   \
+            cleanup();                                                                               \
+            return WB_ERR_HIP;                                                                       \
+        }                                                                                            \
+    } while (0)
+    WB_ST_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    WB_ST_CHECK(hipMalloc(&chn, host.size()));
+    WB_ST_CHECK(hipMalloc(&d_levels, levels.size() * sizeof(WbLevel)));
+    WB_ST_CHECK(hipMalloc(&d_tiles, tiles.size() * sizeof(WbTile)));
+    WB_ST_CHECK(hipMalloc(&det, (size_t)WB_DET_SHARDS * cap * sizeof(WbDet)));
+    WB_ST_CHECK(hipMalloc(&ctr, ctr_words * 4));
+    WB_ST_CHECK(hipMemcpyAsync(chn, host.data(), host.size(), hipMemcpyHostToDevice, st));
+    WB_ST_CHECK(hipMemcpyAsync(d_levels, levels.data(), levels.size() * sizeof(WbLevel), hipMemcpyHostToDevice, st));
+    WB_ST_CHECK(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(WbTile), hipMemcpyHostToDevice, st));
+    struct Result {
+        std::vector<uint32_t> ctr;
+        std::vector<WbDet> det;
+    };
+    auto scan = [&](Result &out) -> int {
+        hipError_t e = hipMemsetAsync(ctr, 0, ctr_words * 4, st);
+        if (e != hipSuccess) return WB_ERR_HIP;
+        const int rc = wb_cascade_launch(st, model, chn, chn_dtype, 0, 1, d_levels, 2, d_tiles, (int)tiles.size(), det, ctr, cap, ctr + WB_DET_SHARDS);
+        if (rc != WB_OK) return rc;
+        out.ctr.resize(ctr_words);
+        e = hipMemcpyAsync(out.ctr.data(), ctr, ctr_words * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return WB_ERR_HIP;
+        out.det.clear();
+        for (int s = 0; s < WB_DET_SHARDS; ++s) {
+            const uint32_t k = out.ctr[s] < cap ? out.ctr[s] : cap;
+            const size_t at = out.det.size();
+            out.det.resize(at + k);
+            if (k && hipMemcpy(out.det.data() + at, det + (size_t)s * cap, (size_t)k * sizeof(WbDet), hipMemcpyDeviceToHost) != hipSuccess) return WB_ERR_HIP;
+        }
+        std::sort(out.det.begin(), out.det.end(), [](const WbDet &p, const WbDet &q) {
+            if (p.level != q.level) return p.level < q.level;
+            if (p.r != q.r) return p.r < q.r;
+            return p.c < q.c;
+        });
+        return WB_OK;
+    };
+    Result want, got;
+    void *const jf = *slot;
+    *slot = nullptr;                                         // the generic kernel ...
+    int rc = scan(want);
+    *slot = jf;                                              // ... and the specialised one
+    int bad = 0;
+    uint64_t n_det = 0;
+    for (int p = 0; rc == WB_OK && p < passes; ++p) {
+        rc = scan(got);
+        if (rc != WB_OK) break;
+        bool same = got.det.size() == want.det.size() && memcmp(got.ctr.data() + WB_DET_SHARDS, want.ctr.data() + WB_DET_SHARDS, 2 * (size_t)T * 4) == 0;
+        for (size_t i = 0; same && i < got.det.size(); ++i)
+            same = got.det[i].level == want.det[i].level && got.det[i].r == want.det[i].r && got.det[i].c == want.det[i].c &&
+                   memcmp(&got.det[i].score, &want.det[i].score, 4) == 0 && got.det[i].image == want.det[i].image;
+        bad += !same;
+        n_det = want.det.size();
+    }
+    cleanup();
+#undef WB_ST_CHECK
+    if (rc != WB_OK) {
+        if (rc == WB_ERR_HIP) wb_set_error("wb_model_specialize (self-test): a HIP call failed");
+        return rc;
+    }
+    if (getenv("WB_JIT_VERBOSE"))
+        fprintf(stderr, "[wb_jit] self-test: %d of %d scans differ from the generic kernel (%llu windows, %llu detections)\n", bad, passes,
+                (unsigned long long)windows, (unsigned long long)n_det);
+    if (bad) {
+        wb_set_error("wb_model_specialize: the specialised kernel disagreed with the generic kernel on %d of %d self-test scans; "
+                     "the model stays on the generic kernel", bad, passes);
+        return WB_ERR_UNSUPPORTED;
+    }
+    return WB_OK;
+}
+
 extern "C" int wb_model_specialize(WbModel *model, int chn_dtype) {
     WB_REQUIRE(model, "wb_model_specialize: null model");
     if (chn_dtype != WB_DTYPE_U8 && chn_dtype != WB_DTYPE_RANK8 && chn_dtype != WB_DTYPE_RANK16) {
@@ -504,9 +637,33 @@ extern "C" int wb_model_specialize(WbModel *model, int chn_dtype) {
     }
     void **slot = ranks16 ? &model->jit_bin16 : ranks ? &model->jit_bin : &model->jit_u8;
     if (*slot) return WB_OK;
-    return wb_jit_get(ranks16 ? model->stages_bin16_host : ranks ? model->stages_bin_host : model->stages_u8_host, model->stage_words,
-                      model->n_stages, model->depth, model->rpw, model->waves, model->C, model->lds_rows, model->lds_pitch, ranks16 ? 2 : 1,
-                      model->lds_stages, slot);
+    const int bit = ranks16 ? 4 : ranks ? 2 : 1;
+    if (model->jit_refused & bit) {
+        wb_set_error("wb_model_specialize: this model's specialised kernel failed its self-test earlier; it stays on the generic kernel");
+        return WB_ERR_UNSUPPORTED;
+    }
+    // the compiler in the process first (its code is what the benchmark runs on), the toolkit's if that build is refused --
+    // by the build check (scratch memory) or by the self-test; WB_JIT_COMPILERS=process / toolkit keeps to one of them
+    const char *only = getenv("WB_JIT_COMPILERS");
+    int rc = WB_ERR_UNSUPPORTED;
+    char first_err[sizeof(g_err)] = "";
+    for (int compiler = 0; compiler < 2; ++compiler) {
+        if (only && strcmp(only, compiler == 0 ? "toolkit" : "process") == 0) continue;
+        rc = wb_jit_get(ranks16 ? model->stages_bin16_host : ranks ? model->stages_bin_host : model->stages_u8_host, model->stage_words,
+                        model->n_stages, model->depth, model->rpw, model->waves, model->C, model->lds_rows, model->lds_pitch,
+                        ranks16 ? 2 : 1, model->lds_stages, compiler, slot);
+        if (rc == WB_OK) {
+            rc = jit_selftest(model, chn_dtype, slot);
+            if (rc == WB_OK) return WB_OK;
+            *slot = nullptr;                               // (the module stays loaded, unused: wb_jit.hip keeps it per process)
+        }
+        if (getenv("WB_JIT_VERBOSE")) fprintf(stderr, "[wb_jit] compiler %d: %s\n", compiler, g_err);
+        if (rc != WB_ERR_UNSUPPORTED) return rc;            // (a compiler or HIP error: report it, do not mask it with the next attempt)
+        if (!first_err[0]) snprintf(first_err, sizeof(first_err), "%s", g_err);
+    }
+    model->jit_refused |= bit;
+    if (first_err[0]) wb_set_error("%s", first_err);
+    return rc;
 }
 
 
@@ -584,6 +741,7 @@ extern "C" int wb_rankgroup_create(const WbModel *const *models, int n, WbRankGr
         }
         v->bin_lut_dev = g->lut_dev;
         v->jit_bin = nullptr;                               // (a specialised kernel bakes the thresholds' indices: per view)
+        v->jit_refused = 0;
         v->bin16_ok = 0;                                    // (the group ranks in one byte; the member's own 16-bit tables are not the union's)
         v->jit_bin16 = nullptr;
         v->stages_bin_dev = nullptr;

@@ -653,7 +653,8 @@ extern "C" int wb_cascade_launch_z(void *stream, const WbModel *model, const voi
         WB_HIP_CHECK(hipGetLastError());
         return WB_OK;
     }
-    const size_t lds = (size_t)(ranks16 ? model->lds_bytes_u16 : a.chn_u8 ? model->lds_bytes_u8 : model->lds_bytes);
+    static const size_t xlds = getenv("WB_CASC_XLDS") ? (size_t)atoi(getenv("WB_CASC_XLDS")) : 0;   // diagnostic: fewer workgroups per CU
+    const size_t lds = (size_t)(ranks16 ? model->lds_bytes_u16 : a.chn_u8 ? model->lds_bytes_u8 : model->lds_bytes) + xlds;
     // the model-specialised kernel, when wb_model_specialize has built one for this kind of byte tile (WB_CASC_JIT=0:
     // diagnostic, stay on the generic kernel)
     static const bool jit_off = getenv("WB_CASC_JIT") && atoi(getenv("WB_CASC_JIT")) == 0;

@@ -88,6 +88,9 @@ __host__ __device__ constexpr size_t wb_lds_stab_off(int eb, int C, int rows, in
 }
 #define WB_LDS_CTL_BYTES 256
 // experiment switches (A/B builds; the defaults are what measured best)
+// every lambda of the kernel body is inlined by decree: left to its cost model the compiler made a real function of
+// run_segments in a 1024-stage depth-3 build, with the captured state handed over through scratch memory
+#define WB_INLINE_LAMBDA __attribute__((always_inline))
 #ifndef WB_TAIL_W
 #define WB_TAIL_W 2          // windows the stage-parallel tail walks side by side
 #endif
@@ -551,7 +554,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     uint32_t entered = 0;                 // windows of this wave entering stage `lane` (phase A)
     // FULL: the cascade has at least S0 stages (the usual case) -- phase A is then straight-line code, no per-stage
     // bound checks: the scheduler is free to request a stage's record while the previous stage is being evaluated
-    auto phase_a = [&](auto full_tag) {
+    auto phase_a = [&](auto full_tag) WB_INLINE_LAMBDA {
         constexpr bool FULL = decltype(full_tag)::value;
         if constexpr (BAKED) {
             wb_static_for<0, S0, G>([&](auto tt) {
@@ -640,7 +643,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     uint2 *wgq = reinterpret_cast<uint2 *>(smem + tile_bytes);
     int t_done = tA;                                              // stages evaluated so far (densely)
     // the workgroup's survivors: total, and how many sit in the waves before this one
-    auto recount = [&]() {
+    auto recount = [&]() WB_INLINE_LAMBDA {
         if (lane == 0) wcnt[wave] = (uint32_t)my_cnt;
         __syncthreads();
         total = 0;
@@ -657,7 +660,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     // stages [t0, t1) on the dense state (hs, lm), records through the scalar cache: the capped queue's fallback.  ONE stage
     // at a time (a group of G records in scalar registers beside phase A's state spilled scalar registers into the hot
     // path: +4 % on every tile for the sake of the rare one that comes here)
-    auto dense_more = [&](int t0, int t1) {
+    auto dense_more = [&](int t0, int t1) WB_INLINE_LAMBDA {
 #pragma nounroll
         for (int t = t0; t < t1; ++t) {
             Stage<D> st;
@@ -767,7 +770,19 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     // ---- phase B: dense re-packed survivors, stage segments [S0,2S0), [2S0,4S0), ...
     int t_begin = t_done;
     // wave-synchronous segments from t_begin up to (at most) t_stop, compacting after each
-    auto run_segments = [&](int t_stop) {
+    // (a specialised build of depth-3 trees, or of a long cascade, keeps every register it may have full of constants; the
+    // two lane addresses the segments use -- queue entry and counter word -- were the values its register allocator then
+    // sent to scratch memory, at any occupancy, and a specialised kernel must not use scratch (wb_jit.hip:
+    // build_without_scratch).  An opaque copy of the lane index makes them cheap to recompute instead.  The 128-stage
+    // depth-2 kernel never spilled them and keeps its code as it was)
+    auto relane = [&]() {
+        int l = lane;
+#ifdef WB_JIT_BAKED
+        if constexpr (BAKED && (D >= 3 || WB_JIT_T > 256)) asm volatile("" : "+v"(l));
+#endif
+        return l;
+    };
+    auto run_segments = [&](int t_stop) WB_INLINE_LAMBDA {
         while (t_begin < t_stop && n_q > 0) {
             // few windows left: the stage-parallel tail is cheaper than walking groups of G
             if ((t_begin >= a.spar[0] && n_q <= a.spar[1]) || (t_begin >= a.spar[2] && n_q <= a.spar[3])) break;
@@ -778,10 +793,10 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
             // the chunks of the queue through the segment's stages.  seg: WbSeg<false> -- the stage range is a run-time
             // value and the records come in through the scalar cache; WbSeg<true, TB, TE> (BAKED builds) -- this very
             // segment [TB, TE) unrolled, its records compile-time constants
-            auto chunk_loop = [&](auto seg) {
+            auto chunk_loop = [&](auto seg) WB_INLINE_LAMBDA {
                 using Seg = decltype(seg);
                 for (int qb = 0; qb < n_q; qb += 64) {
-                    int i = qb + lane;
+                    int i = qb + relane();
                     const bool mine = i < n_q;
                     unsigned long long am = __ballot(mine);                    // alive lanes of this chunk, as a mask
                     uint2 e = mine ? queue[i] : make_uint2(0u, 0u);
@@ -880,7 +895,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
 #undef WB_X
             }
             if (!handled) chunk_loop(WbSeg<false, 0, 0>{});
-            if (entered_b) atomicAdd(&hist[t_begin + lane], entered_b);
+            if (entered_b) atomicAdd(&hist[t_begin + relane()], entered_b);
             n_q = n_out;
             t_begin = t_end;
         }
@@ -925,7 +940,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
 
     // ---- stage-parallel tail: lane i evaluates stage rs + i of a window (two windows side by side)
     // this lane's record for stage rs + lane (the LDS mirror, or HBM when the table is too large for it)
-    auto lane_stage = [&](int rs) {
+    auto lane_stage = [&](int rs) WB_INLINE_LAMBDA {
         Stage<D> st;
         const int t = rs + lane;
         const int tt = t < T ? t : T - 1;
@@ -950,7 +965,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     // lane: rej[w] = a stage rejected it; else h[w] = its score behind the last of them.  entered += the number of
     // these windows that entered stage rs + lane.  A window's chain -- gathers, leaf select, the ripple -- is all
     // latency: two independent chains interleave in the same issue slots.
-    auto pass = [&](auto w_tag, const Stage<D> &st, int nvalid, const int *pos, float *h, bool *rej, uint32_t &entered) {
+    auto pass = [&](auto w_tag, const Stage<D> &st, int nvalid, const int *pos, float *h, bool *rej, uint32_t &entered) WB_INLINE_LAMBDA {
         constexpr int W = decltype(w_tag)::value;
         float pk[W], hk[W];
 #pragma unroll
@@ -1074,7 +1089,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
             const Stage<D> st = lane_stage(rs);
             int n_out = 0;
             uint32_t entered_t = 0;                              // windows that entered stage rs + lane in this pass
-            auto windows = [&](auto w_tag, int i) {
+            auto windows = [&](auto w_tag, int i) WB_INLINE_LAMBDA {
                 constexpr int W = decltype(w_tag)::value;
                 int pos[W];
                 float h[W];
@@ -1147,6 +1162,7 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     return;
 #endif
     uint32_t earlier = 0;
+    if (a.dbg & 64) __syncthreads();          // diagnostic (WB_CASC_DBG=64): every wave stays until all are done, in the SAME binary
     // (LDS serves a wave's operations in order: this wave's additions to hist are performed before its arrival is; the
     // compiler must not move them across it either -- hence the two barriers around a plain atomic)
     asm volatile("" ::: "memory");

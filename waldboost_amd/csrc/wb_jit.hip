@@ -8,6 +8,10 @@
 // for a model that is scanned often enough to be worth ~2 s of compilation.  Compiled code objects are kept in
 // the process and in a cache directory ($WB_JIT_CACHE, default ~/.cache/waldboost_amd), keyed by a hash of the
 // generated source, the target and the hiprtc version.
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE        // dlmopen
+#endif
+#include <dlfcn.h>
 #include <hip/hiprtc.h>
 #include <stdlib.h>
 #include <string.h>
@@ -20,6 +24,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "wb_common.h"
@@ -39,6 +44,77 @@ struct JitKernel {
 
 std::mutex g_mu;
 std::map<uint64_t, JitKernel> g_loaded;      // per process: hash -> loaded module (never unloaded)
+
+// Two compilers can stand behind a specialised kernel (wb_model_specialize tries them in this order, and trusts a build
+// only after it has passed the self-test against the generic kernel):
+//   0  the hiprtc the process already holds -- the library links libhiprtc.so.7; under PyTorch that name resolves to the
+//      copy its wheel bundles (ROCm 7.0 there).  Its code for the 128-stage depth-2 kernel is the one every measurement
+//      of this repository was taken with;
+//   1  the hiprtc of the ROCm toolkit the library was built with (WB_ROCM_LIB_DIR, set by the Makefile from hipcc's
+//      location; WB_HIPRTC_LIB=<file> picks another).  A second libhiprtc + libamd_comgr with the sonames of loaded ones can
+//      only live in a link-map namespace of its own: dlmopen(LM_ID_NEWLM), on first use.
+// Round 4: compiler 0's code for some cascades of depth-3 trees wrote wrong records on nine scans of ten (tests/
+// test_gpu_fuzz.py seeds 558, 569, 644; profiles/r04/jit_selftest.txt) and fails the self-test; compiler 1's code for the
+// same source passed 60 of 60.  The reverse holds for speed on the benchmark's kernel (compiler 1 spills there).
+struct Rtc {
+    decltype(&hiprtcCreateProgram) create = &hiprtcCreateProgram;
+    decltype(&hiprtcCompileProgram) compile = &hiprtcCompileProgram;
+    decltype(&hiprtcGetProgramLogSize) log_size = &hiprtcGetProgramLogSize;
+    decltype(&hiprtcGetProgramLog) log = &hiprtcGetProgramLog;
+    decltype(&hiprtcGetCodeSize) code_size = &hiprtcGetCodeSize;
+    decltype(&hiprtcGetCode) code = &hiprtcGetCode;
+    decltype(&hiprtcDestroyProgram) destroy = &hiprtcDestroyProgram;
+    decltype(&hiprtcGetErrorString) error_string = &hiprtcGetErrorString;
+    decltype(&hiprtcVersion) version = &hiprtcVersion;
+    std::string origin = "process";
+    bool ok = true;
+};
+
+const Rtc &rtc_process() {
+    static const Rtc r;
+    return r;
+}
+
+const Rtc &rtc_toolkit() {
+    static const Rtc r = [] {
+        Rtc y;
+        y.ok = false;
+        const char *env = getenv("WB_HIPRTC_LIB");
+#ifdef WB_ROCM_LIB_DIR
+        const std::string path = env && *env ? std::string(env) : std::string(WB_ROCM_LIB_DIR) + "/libhiprtc.so.7";
+#else
+        const std::string path = env && *env ? std::string(env) : std::string();
+#endif
+        y.origin = path;
+        if (path.empty()) return y;
+        void *h = dlmopen(LM_ID_NEWLM, path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            if (getenv("WB_JIT_VERBOSE")) fprintf(stderr, "[wb_jit] %s: %s\n", path.c_str(), dlerror());
+            return y;
+        }
+        bool ok = true;
+        auto sym = [&](auto &fp, const char *name) {
+            void *p = dlsym(h, name);
+            if (!p) ok = false;
+            else fp = reinterpret_cast<std::remove_reference_t<decltype(fp)>>(p);
+        };
+        sym(y.create, "hiprtcCreateProgram");
+        sym(y.compile, "hiprtcCompileProgram");
+        sym(y.log_size, "hiprtcGetProgramLogSize");
+        sym(y.log, "hiprtcGetProgramLog");
+        sym(y.code_size, "hiprtcGetCodeSize");
+        sym(y.code, "hiprtcGetCode");
+        sym(y.destroy, "hiprtcDestroyProgram");
+        sym(y.error_string, "hiprtcGetErrorString");
+        sym(y.version, "hiprtcVersion");
+        if (!ok && getenv("WB_JIT_VERBOSE")) fprintf(stderr, "[wb_jit] %s lacks a hiprtc entry point\n", path.c_str());
+        y.ok = ok;
+        return y;
+    }();
+    return r;
+}
+
+const Rtc &rtc_of(int which) { return which == 0 ? rtc_process() : rtc_toolkit(); }
 
 uint64_t fnv1a(const void *p, size_t n, uint64_t h = 1469598103934665603ull) {
     const unsigned char *b = static_cast<const unsigned char *>(p);
@@ -68,7 +144,7 @@ std::string segment_list(int T) {
     return s;
 }
 
-std::string make_source(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch, int eb = 1, int lds_stages = -1) {
+std::string make_source(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch, int eb = 1, int lds_stages = -1, int occ_min = 8) {
     std::string s;
     s.reserve(n_words * 12 + 1024);
     s += "#define WB_JIT_BAKED 1\n#define WB_JIT_STAGE_WORDS ";
@@ -78,14 +154,16 @@ std::string make_source(const int32_t *words, size_t n_words, int T, int D, int 
     }
     s += "\n#define WB_JIT_SEGMENTS(X)" + segment_list(T) + "\n";
     s += "#define WB_JIT_LDS_STAGES " + std::to_string(lds_stages < 0 ? T : lds_stages) + "\n";
-    s += "#define WB_JIT_WAVES " + std::to_string(waves) + "\n#define WB_CASC_QFULL " + std::to_string((int)WB_CASC_QFULL) + "\n#define WB_CASC_END_BARRIER " +
-         std::to_string((int)WB_CASC_END_BARRIER) + "\n";
+    // (the ending and the occupancy floor can be overridden per build through WB_JIT_DEFS: diagnostics)
+    s += "#define WB_JIT_WAVES " + std::to_string(waves) + "\n#define WB_CASC_QFULL " + std::to_string((int)WB_CASC_QFULL) +
+         "\n#ifndef WB_CASC_END_BARRIER\n#define WB_CASC_END_BARRIER " + std::to_string((int)WB_CASC_END_BARRIER) +
+         "\n#endif\n#ifndef WB_JIT_OCC_MIN\n#define WB_JIT_OCC_MIN " + std::to_string(occ_min) + "\n#endif\n#ifndef WB_JIT_ATTR_EXTRA\n#define WB_JIT_ATTR_EXTRA\n#endif\n";
     s += "#define WB_JIT_T " + std::to_string(T) + "\n#define WB_JIT_C " + std::to_string(C) + "\n#define WB_JIT_ROWS " +
          std::to_string(rows) + "\n#define WB_JIT_PITCH " + std::to_string(pitch) + "\n";
     s += "#include \"wb_cascade_tile.h\"\n";
     // (8 waves per SIMD, as the generic kernel reaches on its own with 41 registers: the byte tile admits 4 workgroups per CU)
     s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(waves * 64) +
-         ") __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void wb_casc_jit(CascArgs a, const int32_t *stages) {\n"
+         ") __attribute__((" + std::string(occ_min == 8 ? "amdgpu_num_sgpr(80), " : "") + "amdgpu_waves_per_eu(WB_JIT_OCC_MIN, 8) WB_JIT_ATTR_EXTRA)) void wb_casc_jit(CascArgs a, const int32_t *stages) {\n"
          "    cascade_tile_body<" + std::to_string(D) + ", " + std::to_string(rpw) + ", " + std::to_string(waves) +
          ", " + std::to_string(eb) + ", true>(a, stages);\n}\n";
     return s;
@@ -152,13 +230,13 @@ void write_file_atomic(const std::string &dir, const std::string &path, const st
 }
 
 // source -> code object for `arch` (no HIP runtime call: works without a GPU)
-int compile(const std::string &src, const char *arch, std::vector<char> &code, std::string &log) {
+int compile(const Rtc &R, const std::string &src, const char *arch, std::vector<char> &code, std::string &log) {
     hiprtcProgram prog;
     const char *hdr_src[] = {kTileSrc};
     const char *hdr_name[] = {"wb_cascade_tile.h"};
-    hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "wb_casc_jit.hip", 1, hdr_src, hdr_name);
+    hiprtcResult r = R.create(&prog, src.c_str(), "wb_casc_jit.hip", 1, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) {
-        log = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r);
+        log = std::string("hiprtcCreateProgram: ") + R.error_string(r);
         return WB_ERR_HIP;
     }
     const std::string a = std::string("--offload-arch=") + arch;
@@ -177,56 +255,96 @@ int compile(const std::string &src, const char *arch, std::vector<char> &code, s
     }
     std::vector<const char *> opts = {a.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pragma-once-outside-header", "-Wno-inline-asm"};
     for (const std::string &x : extra) opts.push_back(x.c_str());
-    r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+    r = R.compile(prog, (int)opts.size(), opts.data());
     size_t ls = 0;
-    if (hiprtcGetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
+    if (R.log_size(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
         log.resize(ls);
-        (void)hiprtcGetProgramLog(prog, &log[0]);
+        (void)R.log(prog, &log[0]);
     }
     if (getenv("WB_JIT_VERBOSE") && !log.empty()) fprintf(stderr, "[wb_jit] %s\n", log.c_str());
     if (r != HIPRTC_SUCCESS) {
         const size_t at = log.find("error:");                     // (warnings first: show the first error)
         if (at != std::string::npos) log = log.substr(at > 120 ? at - 120 : 0);
-        log = std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(r) + "\n" + log;
-        (void)hiprtcDestroyProgram(&prog);
+        log = std::string("hiprtcCompileProgram: ") + R.error_string(r) + "\n" + log;
+        (void)R.destroy(&prog);
         return WB_ERR_HIP;
     }
     size_t cs = 0;
-    r = hiprtcGetCodeSize(prog, &cs);
+    r = R.code_size(prog, &cs);
     if (r == HIPRTC_SUCCESS) {
         code.resize(cs);
-        r = hiprtcGetCode(prog, code.data());
+        r = R.code(prog, code.data());
     }
-    (void)hiprtcDestroyProgram(&prog);
+    (void)R.destroy(&prog);
     if (const char *d = getenv("WB_JIT_DUMP_DIR")) {            // diagnostic: the generated source and the code object
         const std::string base = std::string(d) + "/wb_casc_jit";
         if (FILE *f = fopen((base + ".hip").c_str(), "w")) { fwrite(src.data(), 1, src.size(), f); fclose(f); }
         if (FILE *f = fopen((base + ".co").c_str(), "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
     }
     if (r != HIPRTC_SUCCESS || code.empty()) {
-        log = std::string("hiprtcGetCode: ") + hiprtcGetErrorString(r);
+        log = std::string("hiprtcGetCode: ") + R.error_string(r);
         return WB_ERR_HIP;
     }
     return WB_OK;
 }
 
+// Bytes of scratch (private segment) per work-item the code object's kernel asks for, from its metadata note (msgpack:
+// the key ".private_segment_fixed_size" followed by an unsigned integer); -1 when the note cannot be read.
+int scratch_bytes(const std::vector<char> &code) {
+    static const char key[] = ".private_segment_fixed_size";
+    const size_t kl = sizeof(key) - 1;
+    for (size_t i = 0; i + kl + 1 <= code.size(); ++i) {
+        if (code[i] != key[0] || memcmp(code.data() + i, key, kl) != 0) continue;
+        const unsigned char *v = reinterpret_cast<const unsigned char *>(code.data()) + i + kl;
+        const size_t left = code.size() - i - kl;
+        if (v[0] <= 0x7f) return v[0];
+        if (v[0] == 0xcc && left >= 2) return v[1];
+        if (v[0] == 0xcd && left >= 3) return (v[1] << 8) | v[2];
+        if (v[0] == 0xce && left >= 5) return (int)(((uint32_t)v[1] << 24) | (v[2] << 16) | (v[3] << 8) | v[4]);
+        return -1;
+    }
+    return -1;
+}
+
+// A specialised kernel keeps its state in registers and LDS, as every cascade kernel of the library does: a build that
+// asks for scratch memory is not used (the generic kernel has none and is then the better kernel anyway).  What used to
+// send two lane addresses of a depth-3 or 1024-stage build to scratch is dealt with in the source (wb_cascade_tile.h:
+// relane, WB_INLINE_LAMBDA); this is the net under it.
+int build_checked(const Rtc &R, const std::string &src, const char *arch, std::vector<char> &code, std::string &log) {
+    const int rc = compile(R, src, arch, code, log);
+    if (rc != WB_OK) return rc;
+    const int sb = scratch_bytes(code);
+    if (sb == 0) return WB_OK;
+    code.clear();
+    log = sb < 0 ? "the code object's metadata has no readable .private_segment_fixed_size"
+                 : "the specialised kernel would spill registers to scratch memory (" + std::to_string(sb) + " bytes per lane)";
+    return WB_ERR_UNSUPPORTED;
+}
+
 }  // namespace
 
 // Build (or fetch) the specialised kernel for one stage table of `M`.  words: (T + G) records of SD dwords as uploaded.
+// compiler: 0 = the hiprtc in the process, 1 = the toolkit's (see Rtc above); WB_ERR_UNSUPPORTED when that one cannot be had.
 int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch, int eb, int lds_stages,
-               void **func_out) {
+               int compiler, void **func_out) {
     *func_out = nullptr;
+    const Rtc &R = rtc_of(compiler);
+    if (!R.ok) {
+        wb_set_error("wb_model_specialize: the toolkit's hiprtc (%s) could not be loaded", R.origin.c_str());
+        return WB_ERR_UNSUPPORTED;
+    }
     hipDeviceProp_t prop;
     int dev = 0;
     WB_HIP_CHECK(hipGetDevice(&dev));
     WB_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     const std::string src = make_source(words, n_words, T, D, rpw, waves, C, rows, pitch, eb, lds_stages);
     int rtc_major = 0, rtc_minor = 0;
-    (void)hiprtcVersion(&rtc_major, &rtc_minor);
+    (void)R.version(&rtc_major, &rtc_minor);
     uint64_t h = fnv1a(src.data(), src.size());
     h = fnv1a(kTileSrc, sizeof(kTileSrc), h);
     h = fnv1a(prop.gcnArchName, strlen(prop.gcnArchName), h);
     h = fnv1a(&rtc_major, sizeof(int), fnv1a(&rtc_minor, sizeof(int), h));
+    h = fnv1a(R.origin.data(), R.origin.size(), h);
     h = fnv1a(&dev, sizeof(int), h);                         // (a module is loaded per device)
     if (const char *e = getenv("WB_JIT_DEFS")) h = fnv1a(e, strlen(e), h);
     std::lock_guard<std::mutex> lock(g_mu);
@@ -239,9 +357,9 @@ int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int 
     snprintf(name, sizeof(name), "%016llx.co", (unsigned long long)h);
     const std::string dir = cache_dir(), path = dir.empty() ? std::string() : dir + "/" + name;
     std::vector<char> code;
-    if (path.empty() || !read_file(path, code) || !plausible_code_object(path, code)) {
+    if (path.empty() || !read_file(path, code) || !plausible_code_object(path, code) || scratch_bytes(code) != 0) {
         std::string log;
-        const int rc = compile(src, prop.gcnArchName, code, log);
+        const int rc = build_checked(R, src, prop.gcnArchName, code, log);
         if (rc != WB_OK) {
             wb_set_error("wb_model_specialize: %.400s", log.c_str());
             return rc;
@@ -251,6 +369,14 @@ int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int 
     JitKernel k;
     hipError_t e = hipModuleLoadData(&k.module, code.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&k.func, k.module, "wb_casc_jit");
+    int local_bytes = 0;
+    if (e == hipSuccess) e = hipFuncGetAttribute(&local_bytes, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k.func);
+    if (e == hipSuccess && local_bytes != 0) {
+        (void)hipModuleUnload(k.module);
+        if (!path.empty()) (void)unlink(path.c_str());
+        wb_set_error("wb_model_specialize: the loaded kernel asks for %d bytes of scratch per lane", local_bytes);
+        return WB_ERR_UNSUPPORTED;
+    }
     if (e != hipSuccess) {
         if (!path.empty()) (void)unlink(path.c_str());          // (a stale or damaged cache entry: compile again next time)
         wb_set_error("wb_model_specialize: loading the compiled kernel failed: %s", hipGetErrorString(e));
@@ -290,10 +416,16 @@ extern "C" int wb_jit_compile_check2(int depth, int n_stages, int elem_bytes, co
     }
     // (as wb_model_create decides it: a stage table beyond 16 KiB is not mirrored in LDS)
     const int lds_stages = n_stages * SD * 4 <= 16 * 1024 ? n_stages : 0;
-    const std::string src = make_source(words.data(), words.size(), n_stages, depth, 4, 8, 4, 4 * 8 + 11, WB_CASC_TC + 12, elem_bytes, lds_stages);
     std::vector<char> code;
     std::string log;
-    const int rc = compile(src, arch, code, log);
+    // (the compiler in the process, or -- WB_JIT_CHECK_COMPILER=1 -- the toolkit's)
+    const Rtc &R = rtc_of(getenv("WB_JIT_CHECK_COMPILER") ? atoi(getenv("WB_JIT_CHECK_COMPILER")) : 0);
+    if (!R.ok) {
+        wb_set_error("wb_jit_compile_check: the toolkit's hiprtc (%s) could not be loaded", R.origin.c_str());
+        return WB_ERR_UNSUPPORTED;
+    }
+    const int rc = build_checked(R, make_source(words.data(), words.size(), n_stages, depth, 4, 8, 4, 4 * 8 + 11, WB_CASC_TC + 12, elem_bytes, lds_stages),
+                                 arch, code, log);
     if (rc != WB_OK) {
         wb_set_error("wb_jit_compile_check: %.400s", log.c_str());
         return rc;
