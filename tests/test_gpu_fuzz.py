@@ -17,8 +17,8 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-def random_configuration(seed):
-    """-> (model, image) of the seed's random configuration."""
+def random_configuration(seed, max_depth=3):
+    """-> (model, image) of the seed's random configuration (trees of depth 1..max_depth)."""
     rng = np.random.default_rng(1000 + seed)
     key, C, _, (lo, hi) = FUNCS[seed % 4]
     func = wb.channels.SPECS[key].func
@@ -37,7 +37,7 @@ def random_configuration(seed):
     T = int(rng.integers(3, 50))
     acc, step = 0.0, float(rng.uniform(-0.5, 0.1))
     for t in range(T):
-        depth = int(rng.integers(1, 4))
+        depth = int(rng.integers(1, max_depth + 1))
         f, th, l, r, p = random_tree_arrays(rng, shape, depth, lo, hi, unbalanced=(depth == 2 and rng.random() < 0.3))
         acc += step
         M.append(wb.DTree(f, th, l, r, p), float("-inf") if rng.random() < 0.2 else float(np.float32(acc)))
@@ -73,3 +73,16 @@ def test_random_configuration_through_the_specialised_kernel(seed):
     assert dm.specialized()
     for k in range(3):
         check_against_oracle(M, img, counters=k == 0)
+
+
+# Nearly every model above holds a depth-3 tree somewhere, so its kernels are the depth-3 ones.  The kernels the benchmark
+# runs on are the depth-2 (and depth-1) ones: the same random configurations with the depth bounded, each through the
+# generic kernel and then through the specialised one.
+@pytest.mark.parametrize("seed", range(700, 748))
+def test_random_configuration_of_bounded_depth_on_both_kernels(seed):
+    M, img = random_configuration(seed, max_depth=1 + seed % 2)
+    check_against_oracle(M, img)
+    dm = M.device_cascade()
+    if dm.specialize():                      # (False: a model without a specialised kernel -- float32 channels without ranks)
+        for k in range(2):
+            check_against_oracle(M, img, counters=False)
