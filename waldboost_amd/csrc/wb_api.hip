@@ -602,6 +602,17 @@ static int jit_selftest(WbModel *model, int chn_dtype, void **slot) {
                    memcmp(&got.det[i].score, &want.det[i].score, 4) == 0 && got.det[i].image == want.det[i].image;
         bad += !same;
         n_det = want.det.size();
+        if (!same && getenv("WB_JIT_VERBOSE")) {              // the first records that differ, both sides
+            int shown = 0;
+            for (size_t i = 0; i < got.det.size() && i < want.det.size() && shown < 6; ++i) {
+                const WbDet &g = got.det[i], &w = want.det[i];
+                if (g.level == w.level && g.r == w.r && g.c == w.c && memcmp(&g.score, &w.score, 4) == 0) continue;
+                fprintf(stderr, "[wb_jit] self-test pass %d, record %zu: specialised (level %d, r %d, c %d, score %.6g) generic (level %d, r %d, c %d, score %.6g)\n",
+                        p, i, g.level, (int)g.r, (int)g.c, g.score, w.level, (int)w.r, (int)w.c, w.score);
+                ++shown;
+            }
+            if (got.det.size() != want.det.size()) fprintf(stderr, "[wb_jit] self-test pass %d: %zu records against %zu\n", p, got.det.size(), want.det.size());
+        }
     }
     cleanup();
 #undef WB_ST_CHECK
