@@ -280,3 +280,45 @@ def test_capture_is_not_disturbed_by_the_cyclic_collector():
         assert gone() is None
     finally:
         gc.enable()
+
+
+def test_every_user_of_an_engines_octaves_keeps_the_clean_keys_promise(monkeypatch):
+    """The fused step holds no memset: the octaves' (min, max) keys must be zero when it starts, and a host-side flag says
+    whether they are.  With WB_CHECK_KEYS the engine reads the keys back before every fused step and raises if the flag
+    lies.  One engine, every path that touches its octaves interleaved: Model.detect (eager, then replaying its graph),
+    channel_pyramid for a caller, the pyramid around a caller's own channel function (bare octave launch + resize_level),
+    the sample miner's scan, and a two-model detect -- the detections in between must stay the oracle's."""
+    from waldboost_amd import engine as E, samples
+    monkeypatch.setattr(E, "_CHECK_KEYS", True)
+    M = wb.load(os.path.join(GOLDEN, "models", MODELS["grad_hist"]))
+    M2 = wb.load(os.path.join(GOLDEN, "models", MODELS["grad_hist"]))
+    M2.theta = [t - 0.25 if np.isfinite(t) else t for t in M2.theta]
+    H, W = 260, 340
+    E._ENGINES.clear()
+    imgs = [synth_image(H, W, 7300 + i) for i in range(3)]
+    refs = [oracle_detect(M, im) for im in imgs]
+
+    def check(k):
+        res = M.detect_raw(imgs[k])
+        assert np.array_equal(res["alive"], refs[k]["alive"]) and np.array_equal(bits(res["scores"]), bits(refs[k]["scores"]))
+        assert np.array_equal(res["r"], refs[k]["r"]) and np.array_equal(res["c"], refs[k]["c"])
+
+    check(0); check(1)                                        # eager, then the captured graph
+    opts = dict(M.channel_opts)
+    levels = [c for c, _ in wb.channels.channel_pyramid(imgs[2], opts)]          # the same engine, for a caller
+    assert len(levels) > 4
+    check(2); check(0)
+
+    def my_channels(im):                                      # a channel function this build has no kernel for
+        return np.stack([im, 255 - im], -1).astype(np.uint8)
+    n = sum(1 for _ in wb.channels.channel_pyramid(imgs[1], dict(opts, channels=my_channels)))
+    assert n == len(levels)
+    check(1)
+    gt = wb.Boxes(np.array([[40, 40, 120, 120]], "f"))
+    mined = list(samples.get_samples_from_image(M, imgs[0], gt, max_tp_candidates=10 ** 6, max_fp_candidates=10 ** 6))   # the miner's scan
+    assert isinstance(mined, list)
+    check(2)
+    both = wb.detect(imgs[0], M, M2)                          # two cascades on one pyramid (its own captured step)
+    assert len(both) == 2
+    check(0); check(1)
+    assert len(E._ENGINES) >= 1

@@ -13,6 +13,7 @@ int wb_cascade_prepare(int depth, int rpw, int waves);  // wb_cascade.hip
 int wb_cascade_group(int depth);                        // stages evaluated per group
 int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch, int eb,
                int lds_stages, int compiler, void **func_out);   // wb_jit.hip
+void wb_jit_release(void *func);                        // wb_jit.hip
 
 static thread_local char g_err[512] = "";
 
@@ -462,6 +463,10 @@ extern "C" int wb_model_destroy(WbModel *model) {
     free(model->stages_bin16_host);
     free(model->stages_u8_host);
     free(model->stages_bin_host);
+    (void)hipDeviceSynchronize();                            // (nothing of the model in flight when its kernels' modules go)
+    wb_jit_release(model->jit_u8);
+    wb_jit_release(model->jit_bin);
+    wb_jit_release(model->jit_bin16);
     void *g[] = {model->g_node_off, model->g_feat, model->g_thr, model->g_left, model->g_right, model->g_pred, model->g_theta};
     for (void *p : g)
         if (p) (void)hipFree(p);
@@ -666,7 +671,9 @@ extern "C" int wb_model_specialize(WbModel *model, int chn_dtype) {
         if (rc == WB_OK) {
             rc = jit_selftest(model, chn_dtype, slot);
             if (rc == WB_OK) return WB_OK;
-            *slot = nullptr;                               // (the module stays loaded, unused: wb_jit.hip keeps it per process)
+            (void)hipDeviceSynchronize();
+            wb_jit_release(*slot);                         // (a build that is not used is not kept)
+            *slot = nullptr;
         }
         if (getenv("WB_JIT_VERBOSE")) fprintf(stderr, "[wb_jit] compiler %d: %s\n", compiler, g_err);
         if (rc != WB_ERR_UNSUPPORTED) return rc;            // (a compiler or HIP error: report it, do not mask it with the next attempt)
@@ -697,6 +704,8 @@ extern "C" int wb_rankgroup_destroy(WbRankGroup *g) {
         if (!v) continue;
         if (v->stages_bin_dev) (void)hipFree(v->stages_bin_dev);
         free(v->stages_bin_host);
+        wb_jit_release(v->jit_bin);                         // (a view's own specialised kernels: its thresholds index the group's union)
+        wb_jit_release(v->jit_u8);
         delete v;
     }
     if (g->lut_dev) (void)hipFree(g->lut_dev);
@@ -752,6 +761,7 @@ extern "C" int wb_rankgroup_create(const WbModel *const *models, int n, WbRankGr
         }
         v->bin_lut_dev = g->lut_dev;
         v->jit_bin = nullptr;                               // (a specialised kernel bakes the thresholds' indices: per view)
+        v->jit_u8 = nullptr;                                // (whatever a view has specialised is the view's to release)
         v->jit_refused = 0;
         v->bin16_ok = 0;                                    // (the group ranks in one byte; the member's own 16-bit tables are not the union's)
         v->jit_bin16 = nullptr;

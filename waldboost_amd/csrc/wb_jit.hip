@@ -40,10 +40,11 @@ const char kTileSrc[] =
 struct JitKernel {
     hipModule_t module = nullptr;
     hipFunction_t func = nullptr;
+    int users = 0;                            // models holding the function (wb_jit_get / wb_jit_release)
 };
 
 std::mutex g_mu;
-std::map<uint64_t, JitKernel> g_loaded;      // per process: hash -> loaded module (never unloaded)
+std::map<uint64_t, JitKernel> g_loaded;      // per process: hash -> loaded module, unloaded when its last model lets go
 
 // Two compilers can stand behind a specialised kernel (wb_model_specialize tries them in this order, and trusts a build
 // only after it has passed the self-test against the generic kernel):
@@ -350,6 +351,7 @@ int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int 
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_loaded.find(h);
     if (it != g_loaded.end()) {
+        ++it->second.users;
         *func_out = it->second.func;
         return WB_OK;
     }
@@ -382,9 +384,25 @@ int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int 
         wb_set_error("wb_model_specialize: loading the compiled kernel failed: %s", hipGetErrorString(e));
         return WB_ERR_HIP;
     }
+    k.users = 1;
     g_loaded[h] = k;
     *func_out = k.func;
     return WB_OK;
+}
+
+// A model lets go of a specialised kernel (wb_model_destroy, a build that failed the self-test): the module is unloaded
+// with its last user.  The caller has made sure nothing of the model is in flight (wb_model_destroy's hipFree calls have).
+void wb_jit_release(void *func) {
+    if (!func) return;
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (auto it = g_loaded.begin(); it != g_loaded.end(); ++it) {
+        if (it->second.func != (hipFunction_t)func) continue;
+        if (--it->second.users <= 0) {
+            (void)hipModuleUnload(it->second.module);
+            g_loaded.erase(it);
+        }
+        return;
+    }
 }
 
 // Compile check without a GPU (the CPU test suite): a synthetic cascade of n_stages random depth-`depth` trees through

@@ -48,6 +48,7 @@ _NO_RANKS = bool(os.environ.get("WB_NO_RANKS"))     # diagnostic: float32 channe
 # Model-specialised cascade kernels (csrc/wb_jit.hip): a cascade that has been scanned this many times on byte tiles is
 # compiled with its stage records as constants (hiprtc, ~2 s once; cached on disk).  WB_CASC_JIT=0: never automatically
 # (DeviceCascade.specialize() still works), WB_CASC_JIT_AFTER=n: after n scans (default 3).
+_CHECK_KEYS = bool(os.environ.get("WB_CHECK_KEYS"))         # diagnostic: verify the clean-keys flag against the device before every fused step
 _NO_FUSED_RESET = bool(os.environ.get("WB_NO_FUSED_RESET"))   # diagnostic: one memset launch per step, as before
 _JIT_AUTO = os.environ.get("WB_CASC_JIT", "1") != "0"
 _JIT_AFTER = int(os.environ.get("WB_CASC_JIT_AFTER", "3"))
@@ -618,6 +619,13 @@ class PyramidEngine:
         if not self._mm_clean and not self.exact_single:
             self.ctrl[: self._mm_words].zero_()
             self._mm_clean = True
+        elif _CHECK_KEYS and not self.exact_single:
+            # WB_CHECK_KEYS=1 (the test suite's interleaving test turns it on): the flag is a host-side promise every user
+            # of the engine's octaves has to keep -- read the keys back and see that it was kept
+            import torch
+            if not torch.cuda.is_current_stream_capturing() and bool(self.ctrl[: self._mm_words].any().item()):
+                raise RuntimeError("the octaves' (min, max) keys are flagged clean but are not zero: some path used the "
+                                   "engine's octaves without going through launch_octaves / clearing _mm_clean")
 
     def ranks_for(self, dm):
         """True when the fused detection path applies: grad_hist channels written straight as threshold ranks of
