@@ -319,6 +319,7 @@ def test_every_user_of_an_engines_octaves_keeps_the_clean_keys_promise(monkeypat
     assert isinstance(mined, list)
     check(2)
     both = wb.detect(imgs[0], M, M2)                          # two cascades on one pyramid (its own captured step)
-    assert len(both) == 2
+    assert both.get().shape[1] == 4 and set(np.unique(both.get_field("label"))) <= {0, 1}
+    wb.detect(imgs[1], M, M2)                                 # (the multi-model step replays its own graph from the second call on)
     check(0); check(1)
     assert len(E._ENGINES) >= 1

@@ -167,3 +167,26 @@ def test_the_disk_cache_of_specialised_kernels_is_bounded_and_checks_what_it_loa
     M = random_model(950, 10, lambda rng: 2)
     assert M.device_cascade().specialize()
     assert_same(M.detect_raw(img), oracle_detect(M, img))
+
+
+def test_a_specialised_kernel_outlives_the_other_models_that_shared_it():
+    """Models with the same content share one loaded module (wb_jit.hip counts its users and unloads it with the last):
+    destroying one of them must leave the other's kernel in place, and a model created afterwards gets a kernel again."""
+    import gc
+    path = os.path.join(GOLDEN, "mixed_d2_T24.pb")
+    img = synth_image(240, 320, 21)
+    A, B = wb.load(path), wb.load(path)
+    ref = oracle_detect(A, img)
+    for M in (A, B):
+        assert M.device_cascade().specialize()
+    assert_same(A.detect_raw(img), ref)
+    del A
+    gc.collect()
+    for _ in range(2):
+        assert_same(B.detect_raw(img), ref)                 # B's function is still loaded
+    del B
+    gc.collect()                                            # last user gone: the module is unloaded ...
+    Cm = wb.load(path)
+    assert Cm.device_cascade().specialize()                 # ... and loaded again (from the disk cache) for the next model
+    for _ in range(2):
+        assert_same(Cm.detect_raw(img), ref)
