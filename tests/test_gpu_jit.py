@@ -170,8 +170,9 @@ def test_the_disk_cache_of_specialised_kernels_is_bounded_and_checks_what_it_loa
 
 
 def test_a_specialised_kernel_outlives_the_other_models_that_shared_it():
-    """Models with the same content share one loaded module (wb_jit.hip counts its users and unloads it with the last):
-    destroying one of them must leave the other's kernel in place, and a model created afterwards gets a kernel again."""
+    """Models with the same content share one loaded module (wb_jit.hip counts its users; an idle module stays loaded until
+    more than WB_JIT_MODULES_MAX are): destroying one model must leave the other's kernel in place, and a model created
+    after both are gone gets its kernel again."""
     import gc
     path = os.path.join(GOLDEN, "mixed_d2_T24.pb")
     img = synth_image(240, 320, 21)
@@ -185,8 +186,8 @@ def test_a_specialised_kernel_outlives_the_other_models_that_shared_it():
     for _ in range(2):
         assert_same(B.detect_raw(img), ref)                 # B's function is still loaded
     del B
-    gc.collect()                                            # last user gone: the module is unloaded ...
+    gc.collect()
     Cm = wb.load(path)
-    assert Cm.device_cascade().specialize()                 # ... and loaded again (from the disk cache) for the next model
+    assert Cm.device_cascade().specialize()
     for _ in range(2):
         assert_same(Cm.detect_raw(img), ref)

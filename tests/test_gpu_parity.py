@@ -531,6 +531,36 @@ def test_multi_model_detect_repeated_calls_replay_one_graph(dtype):
     assert total > 0
 
 
+def test_multi_model_detect_rescans_only_the_cascade_whose_results_did_not_fit(monkeypatch):
+    """waldboost.detect's one-wait sequence with a detection buffer too small for ONE of the two models: that cascade
+    alone is scanned again on the pyramid the sequence left resident (no second channel launch), the other model keeps
+    its results -- and the composition still equals the oracle's, call after call while the buffer grows."""
+    from waldboost_amd import engine as E, _native as nat
+    few, many = random_model(910, 30, 2), random_model(911, 10, 2)
+    many.theta = [float("-inf")] * len(many.theta)            # every window of every level is a detection
+    few.theta = [t + 0.6 if np.isfinite(t) else t for t in few.theta]
+    rs = [1.0, 0.5]
+    E._ENGINES.clear()
+    launches = []
+    real = E.PyramidEngine.launch_channels
+    monkeypatch.setattr(E.PyramidEngine, "launch_channels", lambda self, *a, **k: (launches.append(1), real(self, *a, **k))[1])
+    for i in range(4):
+        img = synth_image(200, 260, 940 + i)
+        if i == 0:
+            wb.detect(img, few, many, response_scale=rs)     # (engine and scan states exist from here on)
+            eng = next(iter(E._ENGINES.values()))
+            eng.det_capacity = 64                            # far below `many`'s detections per shard
+            eng._alloc_det()
+        n0 = len(launches)
+        out = wb.detect(img, few, many, response_scale=rs)
+        refs = [oracle_detect(M, img) for M in (few, many)]
+        assert refs[1]["scores"].size > 64 * nat.WB_DET_SHARDS // 8 and refs[1]["scores"].size > refs[0]["scores"].size
+        boxes, scores, labels = compose_multi((few, many), refs, rs)
+        assert np.array_equal(out.get(), boxes) and np.array_equal(bits(out.get_field("scores")), bits(scores)), f"call {i}"
+        assert np.array_equal(out.get_field("label"), labels), f"call {i}"
+        assert len(launches) - n0 == 1, f"call {i}: the pyramid was built {len(launches) - n0} times"
+
+
 # ------------------------------------------------------------------------------ batches / configs
 @pytest.mark.parametrize("ordered_on_device", [True, False])
 def test_detect_batch_equals_per_image_detect(ordered_on_device, monkeypatch):

@@ -45,7 +45,7 @@ def test_specialised_cascade_kernel_source_compiles_for_gfx950_without_a_gpu(dep
 def test_specialised_kernel_source_compiles_for_16_bit_tiles_and_long_cascades(depth, stages, eb):
     """The same generator for tiles of two-byte elements (WB_DTYPE_RANK16) and for cascades whose stage table is not
     mirrored in LDS (1024 stages: only the first segments are unrolled, the rest runs the kernel's generic loop).
-    The check fails for a build that asks for scratch memory (wb_jit.hip build_without_scratch): depth-3 trees and
+    The check fails for a build that asks for scratch memory (wb_jit.hip build_checked): depth-3 trees and
     1024 stages are the shapes whose builds did, in round 4."""
     lib = nat.load()
     n = C.c_int64()
@@ -78,8 +78,8 @@ def _kernel_scratch_sizes(blob):
 
 def test_no_cascade_kernel_of_the_library_uses_scratch_memory():
     """The cascade kernels keep their state in registers and LDS: `.private_segment_fixed_size` is 0 in the metadata of
-    every one of them (their waves leave one by one; a specialised build WITH scratch memory wrote wrong records under
-    that in round 4 -- see wb_jit.hip build_without_scratch, which refuses such a build).  The only kernels of the library
+    every one of them (so is a specialised build expected to be: wb_model_specialize prefers a scratch-free build, and
+    wb_jit_compile_check fails on one with scratch).  The only kernels of the library
     with scratch are four instances of the channel kernel that spill two or three registers outside their loops."""
     nat.load()
     sizes = _kernel_scratch_sizes(open(nat.LIB_PATH, "rb").read())

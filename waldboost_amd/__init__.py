@@ -59,7 +59,10 @@ def detect(image, *models, channel_opts=None, response_scale=None):
     # ONE wait from the second call on (like Model.detect); model by model where that form does not apply
     fins = eng.detect_multi_run(dms, ranks=group is not None)
     if fins is not None:
-        res = [m._collect(eng, d, eng._casc_state(d), True, fin) for m, d, fin in zip(models, dms, fins)]
+        # (None in a model's place: its results did not fit this time -- that cascade alone is scanned again, on the pyramid
+        # the call left resident)
+        res = [m._collect(eng, d, eng._casc_state(d), True, fin) if fin is not None else None for m, d, fin in zip(models, dms, fins)]
+        res = [r if r is not None else m.scan_engine(eng, view=v) for r, m, v in zip(res, models, views)]
     else:
         if group is not None:
             eng.run_channels(rank_dm=group.views[0], floats=False)

@@ -12,7 +12,7 @@
 int wb_cascade_prepare(int depth, int rpw, int waves);  // wb_cascade.hip
 int wb_cascade_group(int depth);                        // stages evaluated per group
 int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch, int eb,
-               int lds_stages, int compiler, void **func_out);   // wb_jit.hip
+               int lds_stages, int compiler, int allow_scratch, void **func_out);   // wb_jit.hip
 void wb_jit_release(void *func);                        // wb_jit.hip
 
 static thread_local char g_err[512] = "";
@@ -463,7 +463,6 @@ extern "C" int wb_model_destroy(WbModel *model) {
     free(model->stages_bin16_host);
     free(model->stages_u8_host);
     free(model->stages_bin_host);
-    (void)hipDeviceSynchronize();                            // (nothing of the model in flight when its kernels' modules go)
     wb_jit_release(model->jit_u8);
     wb_jit_release(model->jit_bin);
     wb_jit_release(model->jit_bin16);
@@ -658,26 +657,30 @@ extern "C" int wb_model_specialize(WbModel *model, int chn_dtype) {
         wb_set_error("wb_model_specialize: this model's specialised kernel failed its self-test earlier; it stays on the generic kernel");
         return WB_ERR_UNSUPPORTED;
     }
-    // the compiler in the process first (its code is what the benchmark runs on), the toolkit's if that build is refused --
-    // by the build check (scratch memory) or by the self-test; WB_JIT_COMPILERS=process / toolkit keeps to one of them
+    // Candidates in order: the compiler in the process (its code is what the benchmark runs on), then the toolkit's; builds
+    // that keep to registers and LDS first, builds with scratch memory only when no other passes.  A candidate is used once
+    // it has passed the self-test.  WB_JIT_COMPILERS=process / toolkit keeps to one compiler.
     const char *only = getenv("WB_JIT_COMPILERS");
     int rc = WB_ERR_UNSUPPORTED;
     char first_err[sizeof(g_err)] = "";
-    for (int compiler = 0; compiler < 2; ++compiler) {
-        if (only && strcmp(only, compiler == 0 ? "toolkit" : "process") == 0) continue;
-        rc = wb_jit_get(ranks16 ? model->stages_bin16_host : ranks ? model->stages_bin_host : model->stages_u8_host, model->stage_words,
-                        model->n_stages, model->depth, model->rpw, model->waves, model->C, model->lds_rows, model->lds_pitch,
-                        ranks16 ? 2 : 1, model->lds_stages, compiler, slot);
-        if (rc == WB_OK) {
-            rc = jit_selftest(model, chn_dtype, slot);
-            if (rc == WB_OK) return WB_OK;
-            (void)hipDeviceSynchronize();
-            wb_jit_release(*slot);                         // (a build that is not used is not kept)
-            *slot = nullptr;
+    for (int allow_scratch = 0; allow_scratch < 2; ++allow_scratch) {
+        for (int compiler = 0; compiler < 2; ++compiler) {
+            if (only && strcmp(only, compiler == 0 ? "toolkit" : "process") == 0) continue;
+            if (model->jit_refused & (bit << (8 + 4 * compiler))) continue;      // (this compiler's build failed the self-test in the first round)
+            rc = wb_jit_get(ranks16 ? model->stages_bin16_host : ranks ? model->stages_bin_host : model->stages_u8_host, model->stage_words,
+                            model->n_stages, model->depth, model->rpw, model->waves, model->C, model->lds_rows, model->lds_pitch,
+                            ranks16 ? 2 : 1, model->lds_stages, compiler, allow_scratch, slot);
+            if (rc == WB_OK) {
+                rc = jit_selftest(model, chn_dtype, slot);
+                if (rc == WB_OK) return WB_OK;
+                wb_jit_release(*slot);                     // (a build that is not used is idle: wb_jit.hip unloads idle modules when it holds too many)
+                *slot = nullptr;
+                if (rc == WB_ERR_UNSUPPORTED) model->jit_refused |= bit << (8 + 4 * compiler);
+            }
+            if (getenv("WB_JIT_VERBOSE")) fprintf(stderr, "[wb_jit] compiler %d%s: %s\n", compiler, allow_scratch ? " (scratch allowed)" : "", g_err);
+            if (rc != WB_ERR_UNSUPPORTED) return rc;        // (a compiler or HIP error: report it, do not mask it with the next attempt)
+            if (!first_err[0]) snprintf(first_err, sizeof(first_err), "%s", g_err);
         }
-        if (getenv("WB_JIT_VERBOSE")) fprintf(stderr, "[wb_jit] compiler %d: %s\n", compiler, g_err);
-        if (rc != WB_ERR_UNSUPPORTED) return rc;            // (a compiler or HIP error: report it, do not mask it with the next attempt)
-        if (!first_err[0]) snprintf(first_err, sizeof(first_err), "%s", g_err);
     }
     model->jit_refused |= bit;
     if (first_err[0]) wb_set_error("%s", first_err);

@@ -772,9 +772,9 @@ __device__ __forceinline__ void cascade_tile_body(const CascArgs &a, const int32
     // wave-synchronous segments from t_begin up to (at most) t_stop, compacting after each
     // (a specialised build of depth-3 trees, or of a long cascade, keeps every register it may have full of constants; the
     // two lane addresses the segments use -- queue entry and counter word -- were the values its register allocator then
-    // sent to scratch memory, at any occupancy, and a specialised kernel must not use scratch (wb_jit.hip:
-    // build_without_scratch).  An opaque copy of the lane index makes them cheap to recompute instead.  The 128-stage
-    // depth-2 kernel never spilled them and keeps its code as it was)
+    // sent to scratch memory, at any occupancy -- and a specialised kernel is meant to live in registers and LDS (wb_jit.hip:
+    // build_checked).  An opaque copy of the lane index makes them cheap to recompute instead.  The 128-stage depth-2
+    // kernel never spilled them and keeps its code as it was)
     auto relane = [&]() {
         int l = lane;
 #ifdef WB_JIT_BAKED

@@ -41,10 +41,12 @@ struct JitKernel {
     hipModule_t module = nullptr;
     hipFunction_t func = nullptr;
     int users = 0;                            // models holding the function (wb_jit_get / wb_jit_release)
+    uint64_t released = 0;                    // when the last of them let go (a counter): the oldest idle module goes first
 };
 
 std::mutex g_mu;
-std::map<uint64_t, JitKernel> g_loaded;      // per process: hash -> loaded module, unloaded when its last model lets go
+std::map<uint64_t, JitKernel> g_loaded;      // per process: hash -> loaded module
+uint64_t g_release_clock = 0;
 
 // Two compilers can stand behind a specialised kernel (wb_model_specialize tries them in this order, and trusts a build
 // only after it has passed the self-test against the generic kernel):
@@ -307,10 +309,13 @@ int scratch_bytes(const std::vector<char> &code) {
     return -1;
 }
 
-// A specialised kernel keeps its state in registers and LDS, as every cascade kernel of the library does: a build that
-// asks for scratch memory is not used (the generic kernel has none and is then the better kernel anyway).  What used to
-// send two lane addresses of a depth-3 or 1024-stage build to scratch is dealt with in the source (wb_cascade_tile.h:
-// relane, WB_INLINE_LAMBDA); this is the net under it.
+// Scratch memory: every cascade kernel of the library keeps its state in registers and LDS, and a specialised build is
+// expected to.  What used to send two lane addresses of a depth-3 or 1024-stage build to scratch is dealt with in the
+// source (wb_cascade_tile.h: relane, WB_INLINE_LAMBDA).  A build that asks for scratch anyway is not wrong -- it was
+// suspected in round 4 and cleared (profiles/r04/jit_selftest.txt) -- but second choice: wb_model_specialize takes it only
+// when neither compiler has a scratch-free build that passes the self-test (the toolkit's compiler spills 60 bytes per
+// lane in the 128-stage benchmark kernel; under rocprofv3, whose libraries put that compiler into the process first, this
+// is the build that runs).  wb_jit_compile_check (the CPU suite) is strict: scratch fails the check.
 int build_checked(const Rtc &R, const std::string &src, const char *arch, std::vector<char> &code, std::string &log) {
     const int rc = compile(R, src, arch, code, log);
     if (rc != WB_OK) return rc;
@@ -324,10 +329,15 @@ int build_checked(const Rtc &R, const std::string &src, const char *arch, std::v
 
 }  // namespace
 
+namespace {
+void evict_idle_modules();
+}
+
 // Build (or fetch) the specialised kernel for one stage table of `M`.  words: (T + G) records of SD dwords as uploaded.
-// compiler: 0 = the hiprtc in the process, 1 = the toolkit's (see Rtc above); WB_ERR_UNSUPPORTED when that one cannot be had.
+// compiler: 0 = the hiprtc in the process, 1 = the toolkit's (see Rtc above); WB_ERR_UNSUPPORTED when that one cannot be had,
+// and when its build asks for scratch memory while allow_scratch is 0 (the code object stays in the cache either way).
 int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int waves, int C, int rows, int pitch, int eb, int lds_stages,
-               int compiler, void **func_out) {
+               int compiler, int allow_scratch, void **func_out) {
     *func_out = nullptr;
     const Rtc &R = rtc_of(compiler);
     if (!R.ok) {
@@ -359,26 +369,23 @@ int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int 
     snprintf(name, sizeof(name), "%016llx.co", (unsigned long long)h);
     const std::string dir = cache_dir(), path = dir.empty() ? std::string() : dir + "/" + name;
     std::vector<char> code;
-    if (path.empty() || !read_file(path, code) || !plausible_code_object(path, code) || scratch_bytes(code) != 0) {
+    if (path.empty() || !read_file(path, code) || !plausible_code_object(path, code)) {
         std::string log;
-        const int rc = build_checked(R, src, prop.gcnArchName, code, log);
+        const int rc = compile(R, src, prop.gcnArchName, code, log);
         if (rc != WB_OK) {
             wb_set_error("wb_model_specialize: %.400s", log.c_str());
             return rc;
         }
         if (!path.empty()) write_file_atomic(dir, path, code);
     }
+    const int sb = scratch_bytes(code);
+    if (sb != 0 && !allow_scratch) {
+        wb_set_error("wb_model_specialize: this build asks for scratch memory (%d bytes per lane)", sb);
+        return WB_ERR_UNSUPPORTED;
+    }
     JitKernel k;
     hipError_t e = hipModuleLoadData(&k.module, code.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&k.func, k.module, "wb_casc_jit");
-    int local_bytes = 0;
-    if (e == hipSuccess) e = hipFuncGetAttribute(&local_bytes, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k.func);
-    if (e == hipSuccess && local_bytes != 0) {
-        (void)hipModuleUnload(k.module);
-        if (!path.empty()) (void)unlink(path.c_str());
-        wb_set_error("wb_model_specialize: the loaded kernel asks for %d bytes of scratch per lane", local_bytes);
-        return WB_ERR_UNSUPPORTED;
-    }
     if (e != hipSuccess) {
         if (!path.empty()) (void)unlink(path.c_str());          // (a stale or damaged cache entry: compile again next time)
         wb_set_error("wb_model_specialize: loading the compiled kernel failed: %s", hipGetErrorString(e));
@@ -386,24 +393,44 @@ int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int 
     }
     k.users = 1;
     g_loaded[h] = k;
+    evict_idle_modules();
     *func_out = k.func;
     return WB_OK;
 }
 
-// A model lets go of a specialised kernel (wb_model_destroy, a build that failed the self-test): the module is unloaded
-// with its last user.  The caller has made sure nothing of the model is in flight (wb_model_destroy's hipFree calls have).
+// A model lets go of a specialised kernel (wb_model_destroy, a build that failed the self-test).  The module is NOT
+// unloaded on the spot: a hipGraph captured with the kernel may outlive the model by a moment (Python drops a scan state's
+// model and graph in no particular order), and destroying or replaying a graph whose kernel's module is gone is not a
+// risk worth a few hundred KB.  Idle modules are kept, up to WB_JIT_MODULES_MAX (64) loaded ones; beyond that the module
+// that has been idle longest is unloaded when the next one is loaded (a sweep over thousands of models -- training,
+// threshold search -- stays bounded; a model that comes back within the window finds its kernel still loaded).
 void wb_jit_release(void *func) {
     if (!func) return;
     std::lock_guard<std::mutex> lock(g_mu);
-    for (auto it = g_loaded.begin(); it != g_loaded.end(); ++it) {
-        if (it->second.func != (hipFunction_t)func) continue;
-        if (--it->second.users <= 0) {
-            (void)hipModuleUnload(it->second.module);
-            g_loaded.erase(it);
-        }
+    for (auto &kv : g_loaded) {
+        if (kv.second.func != (hipFunction_t)func) continue;
+        if (kv.second.users > 0 && --kv.second.users == 0) kv.second.released = ++g_release_clock;
         return;
     }
 }
+
+namespace {
+// (g_mu held) unload idle modules, longest idle first, while more than the cap are loaded
+void evict_idle_modules() {
+    static const size_t cap = getenv("WB_JIT_MODULES_MAX") ? (size_t)atoi(getenv("WB_JIT_MODULES_MAX")) : 64;
+    bool synced = false;
+    while (g_loaded.size() > cap) {
+        auto victim = g_loaded.end();
+        for (auto it = g_loaded.begin(); it != g_loaded.end(); ++it)
+            if (it->second.users == 0 && (victim == g_loaded.end() || it->second.released < victim->second.released)) victim = it;
+        if (victim == g_loaded.end()) return;                // (every module has a user)
+        if (!synced) (void)hipDeviceSynchronize();           // (nothing of an idle module's last scans in flight)
+        synced = true;
+        (void)hipModuleUnload(victim->second.module);
+        g_loaded.erase(victim);
+    }
+}
+}  // namespace
 
 // Compile check without a GPU (the CPU test suite): a synthetic cascade of n_stages random depth-`depth` trees through
 // the same generator and hiprtc for `arch`.  Returns the code object's size in *code_bytes.

@@ -1119,9 +1119,11 @@ class PyramidEngine:
         """waldboost.detect's whole device sequence for the resident image -- octaves, ONE channel pyramid (as ranks of
         dms[0]'s rank tables -- a rank group's union tables -- or as float32 channels), then per cascade of `dms` its
         scan, wb_det_finish_sorted_launch and the read-back copy -- with ONE wait at its end; from the second call with the
-        same cascades on it is one hipGraph replay.  Returns [what fetch_final returns, per cascade], or None when that
-        form does not apply (more cascades than an engine keeps states for, a pyramid beyond the sort key's fields, an
-        overflowing detection buffer, more detections than one read-back holds): the caller then scans model by model."""
+        same cascades on it is one hipGraph replay.  Returns [what fetch_final returns, per cascade] -- None in the place of
+        a cascade whose results did not fit (an overflowing detection buffer, more detections than one read-back holds): the
+        pyramid stays resident and the caller scans that cascade alone again --, or None when the form does not apply at all
+        (more cascades than an engine keeps states for, a pyramid beyond the sort key's fields, a sequence that kept missing
+        lately): the caller then builds the pyramid and scans model by model."""
         import torch
         if not self._final_ready() or not 0 < len(dms) <= 4 or len({id(d) for d in dms}) != len(dms):
             return None
@@ -1161,16 +1163,25 @@ class PyramidEngine:
             self.rank_owner = dms[0].rank_key if ranks else None
         self._fetch_ev.record()
         self._fetch_ev.synchronize()
-        out = []
+        out, missed = [], False
         for d, stt in zip(dms, stts):
             hdr, keys, boxes, scores = stt["h_final_views"]
             total, worst = int(hdr[0]), int(hdr[1])
             if worst > self.detb.cap or total > self._FETCH_ROWS:
-                st["fails"] += 1                              # (tried again after 16, 32, 64 ... calls)
-                st["skip"] = min(8 << st["fails"], 4096)
-                return None
-            out.append((keys[:total], boxes, scores, stt["h_alive"][:, :, :d.n_stages].astype(np.int64), bool(hdr[3])))
-        st["fails"] = 0
+                # this cascade's results did not fit (a shard overflowed, or more detections than one read-back holds):
+                # None in its place -- the caller scans THAT cascade again on the pyramid this call left resident
+                # (Model.scan_engine: run_cascade + fetch, which grows the buffer); the others keep what they have
+                missed = True
+                out.append(None)
+            else:
+                out.append((keys[:total], boxes, scores, stt["h_alive"][:, :, :d.n_stages].astype(np.int64), bool(hdr[3])))
+        if missed:
+            st["fails"] += 1                                  # (the whole sequence is tried again after 16, 32, 64 ... calls)
+            st["skip"] = min(8 << st["fails"], 4096)
+            # (the re-scans may reuse read-back buffers before the caller has collected the fitted results: hand out copies)
+            out = [None if f is None else (f[0].copy(), np.array(f[1][:f[0].size]), np.array(f[2][:f[0].size]), f[3], f[4]) for f in out]
+        else:
+            st["fails"] = 0
         return out
 
     def detect_collect(self, dm, token, stream=None):
