@@ -371,6 +371,9 @@ def main():
         except Exception as exc:                              # (a compiler failure leaves the generic kernel: say so, go on)
             print(f"bench: model specialisation failed, staying on the generic cascade kernel: {exc}", file=sys.stderr)
         t_jit = time.perf_counter() - t_jit
+        if not jit:                                           # (refused: no build passed the self-test against the generic kernel)
+            from waldboost_amd import _native as _nat
+            print(f"bench: no specialised cascade kernel for this model, the line is timed on the generic one: {_nat.last_error()}", file=sys.stderr)
     B, P = args.batch, max(1, args.pool)
     engines = []
     for i in range(P):
