@@ -42,6 +42,7 @@ struct JitKernel {
     hipFunction_t func = nullptr;
     int users = 0;                            // models holding the function (wb_jit_get / wb_jit_release)
     uint64_t released = 0;                    // when the last of them let go (a counter): the oldest idle module goes first
+    int scratch = 0;                          // bytes of scratch memory per lane the build asks for
 };
 
 std::mutex g_mu;
@@ -361,6 +362,10 @@ int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int 
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_loaded.find(h);
     if (it != g_loaded.end()) {
+        if (it->second.scratch != 0 && !allow_scratch) {
+            wb_set_error("wb_model_specialize: this build asks for scratch memory (%d bytes per lane)", it->second.scratch);
+            return WB_ERR_UNSUPPORTED;
+        }
         ++it->second.users;
         *func_out = it->second.func;
         return WB_OK;
@@ -392,6 +397,7 @@ int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int 
         return WB_ERR_HIP;
     }
     k.users = 1;
+    k.scratch = sb;
     g_loaded[h] = k;
     evict_idle_modules();
     *func_out = k.func;
