@@ -657,10 +657,16 @@ extern "C" int wb_model_specialize(WbModel *model, int chn_dtype) {
         wb_set_error("wb_model_specialize: this model's specialised kernel failed its self-test earlier; it stays on the generic kernel");
         return WB_ERR_UNSUPPORTED;
     }
-    // Candidates in order: the compiler in the process (its code is what the benchmark runs on), then the toolkit's; builds
-    // that keep to registers and LDS first, builds with scratch memory only when no other passes.  A candidate is used once
-    // it has passed the self-test.  WB_JIT_COMPILERS=process / toolkit keeps to one compiler.
-    const char *only = getenv("WB_JIT_COMPILERS");
+    // Candidates: the build of the compiler in the process (its code is what the benchmark runs on) that keeps to registers
+    // and LDS, then its build with scratch memory; a candidate is used once it has passed the self-test.  With
+    // WB_JIT_COMPILERS=both the toolkit's compiler (wb_jit.hip: a second hiprtc in a link-map namespace of its own) is a
+    // second source of candidates, =toolkit the only one.  It is NOT on by default: its code passed where the first
+    // compiler's failed (60 scans of 60), but the compiler itself, running on that namespace's private copy of libc,
+    // crashed with a segmentation fault in about every second run of the full GPU test suite (never in a short process;
+    // the backtrace ends in libhiprtc.so.7 -> libc of the namespace).  A model whose first-compiler build fails the
+    // self-test stays on the generic kernel.
+    const char *which = getenv("WB_JIT_COMPILERS");
+    const char *only = which && strcmp(which, "both") == 0 ? nullptr : which ? which : "process";
     int rc = WB_ERR_UNSUPPORTED;
     char first_err[sizeof(g_err)] = "";
     for (int allow_scratch = 0; allow_scratch < 2; ++allow_scratch) {

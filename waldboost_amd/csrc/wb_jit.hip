@@ -49,17 +49,16 @@ std::mutex g_mu;
 std::map<uint64_t, JitKernel> g_loaded;      // per process: hash -> loaded module
 uint64_t g_release_clock = 0;
 
-// Two compilers can stand behind a specialised kernel (wb_model_specialize tries them in this order, and trusts a build
-// only after it has passed the self-test against the generic kernel):
+// Two compilers can stand behind a specialised kernel:
 //   0  the hiprtc the process already holds -- the library links libhiprtc.so.7; under PyTorch that name resolves to the
-//      copy its wheel bundles (ROCm 7.0 there).  Its code for the 128-stage depth-2 kernel is the one every measurement
-//      of this repository was taken with;
+//      copy its wheel bundles (ROCm 7.0 there), under rocprofv3 to the toolkit's.  The default, and the only one by default;
 //   1  the hiprtc of the ROCm toolkit the library was built with (WB_ROCM_LIB_DIR, set by the Makefile from hipcc's
-//      location; WB_HIPRTC_LIB=<file> picks another).  A second libhiprtc + libamd_comgr with the sonames of loaded ones can
-//      only live in a link-map namespace of its own: dlmopen(LM_ID_NEWLM), on first use.
+//      location; WB_HIPRTC_LIB=<file> picks another), for WB_JIT_COMPILERS=both / toolkit.  A second libhiprtc +
+//      libamd_comgr with the sonames of loaded ones can only live in a link-map namespace of its own: dlmopen(LM_ID_NEWLM),
+//      on first use -- which also gives it a private copy of libc, and that is where it crashed in long processes.
 // Round 4: compiler 0's code for some cascades of depth-3 trees wrote wrong records on nine scans of ten (tests/
 // test_gpu_fuzz.py seeds 558, 569, 644; profiles/r04/jit_selftest.txt) and fails the self-test; compiler 1's code for the
-// same source passed 60 of 60.  The reverse holds for speed on the benchmark's kernel (compiler 1 spills there).
+// same source passed 60 of 60.  wb_model_specialize trusts a build only after the self-test, whichever compiler made it.
 struct Rtc {
     decltype(&hiprtcCreateProgram) create = &hiprtcCreateProgram;
     decltype(&hiprtcCompileProgram) compile = &hiprtcCompileProgram;
@@ -404,12 +403,15 @@ int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int 
     return WB_OK;
 }
 
-// A model lets go of a specialised kernel (wb_model_destroy, a build that failed the self-test).  The module is NOT
-// unloaded on the spot: a hipGraph captured with the kernel may outlive the model by a moment (Python drops a scan state's
-// model and graph in no particular order), and destroying or replaying a graph whose kernel's module is gone is not a
-// risk worth a few hundred KB.  Idle modules are kept, up to WB_JIT_MODULES_MAX (64) loaded ones; beyond that the module
-// that has been idle longest is unloaded when the next one is loaded (a sweep over thousands of models -- training,
-// threshold search -- stays bounded; a model that comes back within the window finds its kernel still loaded).
+// A model lets go of a specialised kernel (wb_model_destroy, a build that failed the self-test): its module becomes idle.
+// Idle modules are NOT unloaded by default.  Round 4 tried both obvious policies -- unload with the last user, and unload
+// the longest-idle module once more than 64 are loaded -- and each crashed the GPU test suite once in a few runs with a
+// segmentation fault inside wb_model_specialize, at the point where a module was unloaded (some three hundred tests, dozens
+// of captured hipGraphs and ~70 modules into the process; never in a small process, never under the debugger).  What
+// hipModuleUnload trips over was not found, and a few hundred KB per dead model do not justify a crash: the modules of a
+// process stay loaded, as in rounds 1-3.  WB_JIT_MODULES_MAX=<n> turns the eviction on for callers who sweep over
+// thousands of models and prefer the risk (n loaded modules at most; the longest-idle one goes first, behind a device
+// synchronisation).
 void wb_jit_release(void *func) {
     if (!func) return;
     std::lock_guard<std::mutex> lock(g_mu);
@@ -423,7 +425,8 @@ void wb_jit_release(void *func) {
 namespace {
 // (g_mu held) unload idle modules, longest idle first, while more than the cap are loaded
 void evict_idle_modules() {
-    static const size_t cap = getenv("WB_JIT_MODULES_MAX") ? (size_t)atoi(getenv("WB_JIT_MODULES_MAX")) : 64;
+    static const size_t cap = getenv("WB_JIT_MODULES_MAX") ? (size_t)atoi(getenv("WB_JIT_MODULES_MAX")) : 0;
+    if (cap == 0) return;                                    // (default: never unload)
     bool synced = false;
     while (g_loaded.size() > cap) {
         auto victim = g_loaded.end();
