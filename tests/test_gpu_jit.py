@@ -170,8 +170,8 @@ def test_the_disk_cache_of_specialised_kernels_is_bounded_and_checks_what_it_loa
 
 
 def test_a_specialised_kernel_outlives_the_other_models_that_shared_it():
-    """Models with the same content share one loaded module (wb_jit.hip counts its users; idle modules stay loaded unless
-    WB_JIT_MODULES_MAX says otherwise): destroying one model must leave the other's kernel in place, and a model created
+    """Models with the same content share one loaded module (wb_jit.hip counts its users; an idle module stays loaded until more than
+    WB_JIT_MODULES_MAX are): destroying one model must leave the other's kernel in place, and a model created
     after both are gone gets its kernel again."""
     import gc
     path = os.path.join(GOLDEN, "mixed_d2_T24.pb")

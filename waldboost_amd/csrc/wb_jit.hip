@@ -404,14 +404,10 @@ int wb_jit_get(const int32_t *words, size_t n_words, int T, int D, int rpw, int 
 }
 
 // A model lets go of a specialised kernel (wb_model_destroy, a build that failed the self-test): its module becomes idle.
-// Idle modules are NOT unloaded by default.  Round 4 tried both obvious policies -- unload with the last user, and unload
-// the longest-idle module once more than 64 are loaded -- and each crashed the GPU test suite once in a few runs with a
-// segmentation fault inside wb_model_specialize, at the point where a module was unloaded (some three hundred tests, dozens
-// of captured hipGraphs and ~70 modules into the process; never in a small process, never under the debugger).  What
-// hipModuleUnload trips over was not found, and a few hundred KB per dead model do not justify a crash: the modules of a
-// process stay loaded, as in rounds 1-3.  WB_JIT_MODULES_MAX=<n> turns the eviction on for callers who sweep over
-// thousands of models and prefer the risk (n loaded modules at most; the longest-idle one goes first, behind a device
-// synchronisation).
+// It is not unloaded on the spot -- a hipGraph captured with the kernel may outlive the model by a moment (Python drops a
+// scan state's model and graph in no particular order) -- but when the next module is loaded and more than
+// WB_JIT_MODULES_MAX (64) are: the longest-idle one goes first, behind a device synchronisation.  A sweep over thousands
+// of models (training, threshold search) stays bounded; a model that comes back within the window finds its kernel loaded.
 void wb_jit_release(void *func) {
     if (!func) return;
     std::lock_guard<std::mutex> lock(g_mu);
@@ -425,8 +421,8 @@ void wb_jit_release(void *func) {
 namespace {
 // (g_mu held) unload idle modules, longest idle first, while more than the cap are loaded
 void evict_idle_modules() {
-    static const size_t cap = getenv("WB_JIT_MODULES_MAX") ? (size_t)atoi(getenv("WB_JIT_MODULES_MAX")) : 0;
-    if (cap == 0) return;                                    // (default: never unload)
+    static const size_t cap = getenv("WB_JIT_MODULES_MAX") ? (size_t)atoi(getenv("WB_JIT_MODULES_MAX")) : 64;
+    if (cap == 0) return;                                    // (0: never unload)
     bool synced = false;
     while (g_loaded.size() > cap) {
         auto victim = g_loaded.end();
