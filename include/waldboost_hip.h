@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define WB_ABI_VERSION 7
+#define WB_ABI_VERSION 8
 
 #define WB_OK 0
 #define WB_ERR_INVALID (-1)     /* bad argument / malformed model */
@@ -301,6 +301,10 @@ int wb_model_info(const WbModel *model, WbModelInfo *info);
  * on for that dtype; results are bit-identical to the generic kernel's.  WB_ERR_UNSUPPORTED for float32 channels and
  * for models on the node-walk kernel; a failed compilation leaves the model on the generic kernel. */
 int wb_model_specialize(WbModel *model, int chn_dtype);
+/* ABI 8.  Make wb_cascade_launch ignore (enable = 0) or use again (1) the specialised kernels this model has loaded: with
+ * them off the generic kernel scans.  For callers that cross-check a specialised kernel on their own data before they
+ * rely on it (the Python engine does, on the image at hand, right after wb_model_specialize), or retire one. */
+int wb_model_use_specialized(WbModel *model, int enable);
 
 /* Several cascades over ONE pyramid of threshold ranks (waldboost.detect(image, *models), reference __init__.py:120-124:
  * the channels are computed once for all models): one rank table per channel from the UNION of the members'

@@ -191,3 +191,46 @@ def test_a_specialised_kernel_outlives_the_other_models_that_shared_it():
     assert Cm.device_cascade().specialize()
     for _ in range(2):
         assert_same(Cm.detect_raw(img), ref)
+
+
+def test_a_fresh_specialised_kernel_is_cross_checked_on_the_first_real_image(monkeypatch, caplog):
+    """Model.detect builds the specialised kernel on its second call, before it captures its graph -- and right there runs
+    the step twice more on the image at hand: specialised kernel against generic kernel, records and alive counts compared
+    on the device (PyramidEngine.live_check).  Agreement: the kernel is kept.  A disagreement (forced here by corrupting
+    what the check reads back from the specialised pass) switches it off for the cascade, with a warning, and every result
+    stays the oracle's."""
+    import logging
+    from waldboost_amd import engine as E
+    path = os.path.join(GOLDEN, "mixed_d2_T24.pb")
+    imgs = [synth_image(240, 320, 30 + i) for i in range(3)]
+    # 1. the normal case
+    E._ENGINES.clear()
+    M = wb.load(path)
+    refs = [oracle_detect(M, im) for im in imgs]
+    dm = M.device_cascade()
+    kind = dm.rank_dtype if dm.rank_dtype is not None else nat.WB_DTYPE_U8
+    for im, ref in zip(imgs, refs):
+        assert_same(M.detect_raw(im), ref)
+    assert kind in dm.specialized() and dm.live_checks_left(kind) == 0 and not dm.__dict__.get("_spec_off")
+    # 2. a kernel that "disagrees"
+    E._ENGINES.clear()
+    M2 = wb.load(path)
+    dm2 = M2.device_cascade()
+    real, calls = E.sort_records, []
+
+    def corrupted(d):
+        out = real(d)
+        calls.append(1)
+        if len(calls) == 1 and out.shape[0]:                 # the specialised pass of the first check
+            out = out.clone()
+            out[0, 3] += 1                                   # one score bit
+        return out
+    monkeypatch.setattr(E, "sort_records", corrupted)
+    with caplog.at_level(logging.WARNING, logger=E._log.name):
+        for im, ref in zip(imgs, refs):
+            assert_same(M2.detect_raw(im), ref)
+    assert dm2.__dict__.get("_spec_off") is True and dm2.live_checks_left(kind) == 0
+    assert any("switched off" in r.getMessage() for r in caplog.records)
+    monkeypatch.setattr(E, "sort_records", real)
+    for im, ref in zip(imgs, refs):                          # the generic kernel from here on
+        assert_same(M2.detect_raw(im), ref)

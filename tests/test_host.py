@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(nat.SYMBOLS), (declared ^ set(nat.SYMBOLS))
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.wb_abi_version() == nat.WB_ABI_VERSION == 7
+    assert lib.wb_abi_version() == nat.WB_ABI_VERSION == 8
     assert lib.wb_last_error() is not None
 
 

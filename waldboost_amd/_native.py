@@ -20,7 +20,7 @@ WB_ERR_INVALID, WB_ERR_HIP, WB_ERR_UNSUPPORTED = -1, -2, -3
 WB_DET_SHARDS = 64
 WB_DTYPE_I64, WB_DTYPE_U64, WB_DTYPE_BOOL, WB_DTYPE_F16 = 9, 10, 11, 12
 WB_CHN_GRAD_HIST, WB_CHN_GRAD_HIST_4_U1, WB_CHN_GRAD_MAG_U1, WB_CHN_GRAD_MAG = 0, 1, 2, 3
-WB_ABI_VERSION = 7
+WB_ABI_VERSION = 8
 
 # numpy mirrors of the ABI structs (sizes asserted against the header's comments)
 LEVEL_DTYPE = np.dtype([
@@ -67,6 +67,7 @@ SYMBOLS = {
     "wb_model_destroy": (C.c_int, [_P]),
     "wb_model_info": (C.c_int, [_P, C.POINTER(WbModelInfo)]),
     "wb_model_specialize": (C.c_int, [_P, C.c_int]),
+    "wb_model_use_specialized": (C.c_int, [_P, C.c_int]),
     "wb_jit_compile_check": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int64)]),
     "wb_jit_compile_check2": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int64)]),
     "wb_rankgroup_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(_P)]),

@@ -491,6 +491,14 @@ extern "C" int wb_model_info(const WbModel *model, WbModelInfo *info) {
 
 // The model-specialised kernel for one kind of byte tile (wb_jit.hip): compiled with hiprtc on first use (a couple of
 // seconds), then taken from the process / disk cache.  wb_cascade_launch uses it from then on for that channel dtype.
+// The loaded specialised kernels of a model off (0) or on (1) for wb_cascade_launch: off, the generic kernel scans -- what a
+// caller needs to cross-check a specialised kernel on its own data (engine.py: _live_check), or to retire one it distrusts.
+extern "C" int wb_model_use_specialized(WbModel *model, int enable) {
+    WB_REQUIRE(model, "wb_model_use_specialized: null model");
+    model->jit_off = enable ? 0 : 1;
+    return WB_OK;
+}
+
 // A specialised kernel is run-time compiled code for ONE model: before it is trusted it scans a synthetic two-level
 // pyramid of byte tiles several times and must give, every time, exactly what the generic kernel of the library gives on
 // the same bytes: per-stage alive counts and the detection records (window, score bits).  The levels hold tiles of every
@@ -771,6 +779,7 @@ extern "C" int wb_rankgroup_create(const WbModel *const *models, int n, WbRankGr
         v->bin_lut_dev = g->lut_dev;
         v->jit_bin = nullptr;                               // (a specialised kernel bakes the thresholds' indices: per view)
         v->jit_u8 = nullptr;                                // (whatever a view has specialised is the view's to release)
+        v->jit_off = 0;
         v->jit_refused = 0;
         v->bin16_ok = 0;                                    // (the group ranks in one byte; the member's own 16-bit tables are not the union's)
         v->jit_bin16 = nullptr;

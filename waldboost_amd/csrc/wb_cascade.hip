@@ -658,7 +658,7 @@ extern "C" int wb_cascade_launch_z(void *stream, const WbModel *model, const voi
     // the model-specialised kernel, when wb_model_specialize has built one for this kind of byte tile (WB_CASC_JIT=0:
     // diagnostic, stay on the generic kernel)
     static const bool jit_off = getenv("WB_CASC_JIT") && atoi(getenv("WB_CASC_JIT")) == 0;
-    if (void *jf = a.chn_u8 && !jit_off ? (ranks16 ? model->jit_bin16 : ranks ? model->jit_bin : model->jit_u8) : nullptr) {
+    if (void *jf = a.chn_u8 && !jit_off && !model->jit_off ? (ranks16 ? model->jit_bin16 : ranks ? model->jit_bin : model->jit_u8) : nullptr) {
         const int32_t *stages = a.stages;
         void *params[] = {&a, &stages};
         WB_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)jf, grid.x, grid.y, 1, (unsigned)model->waves * 64, 1, 1, (unsigned)lds, st,

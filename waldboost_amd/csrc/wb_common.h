@@ -151,6 +151,7 @@ struct WbModel {
     int32_t *stages_u8_host, *stages_bin_host;   // host copies of the two byte-tile tables the generator bakes in
     size_t stage_words;                          // (n_stages + G) * stage_dwords
     void *jit_u8, *jit_bin;
+    int jit_off;                // 1 = wb_cascade_launch ignores the loaded specialised kernels (wb_model_use_specialized)
     int jit_refused;            // bit per byte-tile kind (1 uint8, 2 ranks, 4 16-bit ranks): its specialised kernel was built and failed the self-test
     // trees deeper than WB_CASC_MAX_DEPTH: generic node-walk kernel on the reference's own flat arrays
     int generic;                // 1 = use cascade_generic_kernel

@@ -48,6 +48,9 @@ _NO_RANKS = bool(os.environ.get("WB_NO_RANKS"))     # diagnostic: float32 channe
 # Model-specialised cascade kernels (csrc/wb_jit.hip): a cascade that has been scanned this many times on byte tiles is
 # compiled with its stage records as constants (hiprtc, ~2 s once; cached on disk).  WB_CASC_JIT=0: never automatically
 # (DeviceCascade.specialize() still works), WB_CASC_JIT_AFTER=n: after n scans (default 3).
+# A freshly specialised cascade kernel is cross-checked against the generic kernel on the first real image it meets (this
+# many times; 0 = never): the library's self-test (wb_model_specialize) runs on synthetic bytes, this one on the caller's.
+_LIVE_CHECKS = int(os.environ.get("WB_JIT_LIVE_CHECKS", "2"))
 _CHECK_KEYS = bool(os.environ.get("WB_CHECK_KEYS"))         # diagnostic: verify the clean-keys flag against the device before every fused step
 _NO_FUSED_RESET = bool(os.environ.get("WB_NO_FUSED_RESET"))   # diagnostic: one memset launch per step, as before
 _JIT_AUTO = os.environ.get("WB_CASC_JIT", "1") != "0"
@@ -202,11 +205,22 @@ class DeviceCascade:
         specialised kernel (node-walk models, cascades beyond the LDS mirror); raises NativeError if the compiler fails."""
         if chn_dtype is None:
             chn_dtype = self.rank_dtype if self.rank_dtype is not None else nat.WB_DTYPE_U8
+        had = chn_dtype in self.specialized()
         rc = self._lib.wb_model_specialize(self.handle, chn_dtype)
         if rc == nat.WB_ERR_UNSUPPORTED:
             return False
         nat.check(rc, "wb_model_specialize")
+        if not had:
+            self.__dict__.setdefault("_live_left", {})[chn_dtype] = _LIVE_CHECKS      # (PyramidEngine.live_check)
         return True
+
+    def use_specialized(self, enable):
+        """The loaded specialised kernels on / off for every later scan of this cascade (off: the generic kernel)."""
+        nat.check(self._lib.wb_model_use_specialized(self.handle, 1 if enable else 0), "wb_model_use_specialized")
+        self.__dict__["_spec_off"] = not enable
+
+    def live_checks_left(self, chn_dtype):
+        return 0 if self.__dict__.get("_spec_off") else self.__dict__.get("_live_left", {}).get(chn_dtype, 0)
 
     def note_scan(self, chn_dtype, force=False):
         """Called by the engine before a scan on byte tiles: after _JIT_AFTER scans (force: now -- Model.detect is about
@@ -1061,6 +1075,35 @@ class PyramidEngine:
             out.append((keys[:n_b], boxes[:n_b], scores[:n_b]))
         return out, self._h_alive.numpy()[:, :, :T].astype(np.int64)
 
+    def live_check(self, dm):
+        """A cascade whose specialised kernel has just been built, on the image(s) resident in this engine: the whole step
+        with the specialised kernel, then the cascade alone again with the generic kernel on the same channels; per-stage
+        alive counts and the ordered detection records must be identical.  If they are not, the specialised kernel is
+        switched off for this cascade for good (a warning says so) -- the step's buffers hold the generic kernel's results
+        either way.  Runs _LIVE_CHECKS times per cascade and tile kind, outside captures; costs one extra step each."""
+        import torch
+        dtype = dm.rank_dtype if self.ranks_for(dm) else self.spec.wb_dtype
+        if dm.live_checks_left(dtype) <= 0 or dtype not in dm.specialized() or torch.cuda.is_current_stream_capturing():
+            return
+        left = dm.__dict__["_live_left"]
+        while left.get(dtype, 0) > 0:
+            left[dtype] -= 1
+            stt = self.run(dm)                                       # specialised kernel
+            if int(self.detb.counts.max().item()) > self.detb.cap:
+                return                                                # (overflowing buffer: the caller grows it; check another time)
+            spec = (sort_records(self.detb.compact()).clone(), stt["alive"].clone())
+            dm.use_specialized(False)
+            self.run_cascade(dm, ranks=stt["ranks"])                  # generic kernel, same channels
+            gen = (sort_records(self.detb.compact()), stt["alive"])
+            same = spec[0].shape == gen[0].shape and bool(torch.equal(spec[0], gen[0])) and bool(torch.equal(spec[1], gen[1]))
+            if not same:
+                left[dtype] = 0
+                _log.warning("cascade of %d stages, depth %d: its model-specialised kernel disagrees with the generic kernel on "
+                             "this image (%d against %d detections); the specialised kernel is switched off for this cascade",
+                             dm.n_stages, dm.depth, int(spec[0].shape[0]), int(gen[0].shape[0]))
+                return                                                # (stays off)
+            dm.use_specialized(True)
+
     def detect_run(self, dm):
         """Model.detect's whole device sequence for the resident image -- one memset, octaves, channels, cascade,
         wb_det_finish_sorted_launch (which also carries alive[] behind the scores), the ONE read-back copy -- and its one synchronisation; from the second call with the
@@ -1081,6 +1124,7 @@ class PyramidEngine:
             # (the first call ran eagerly: every lazily allocated buffer exists, the kernels are loaded)
             # a cascade that is scanned again is worth its specialised kernel -- built now, so that the graph holds it
             dm.note_scan(dm.rank_dtype if self.ranks_for(dm) else self.spec.wb_dtype, force=True)
+            self.live_check(dm)               # (a kernel built just now meets its first real image: cross-checked before the capture)
             g = torch.cuda.CUDAGraph()
             self.ensure_clean_keys()          # (the captured step holds no memset: see run)
             torch.cuda.synchronize()
@@ -1107,6 +1151,7 @@ class PyramidEngine:
             step = None
         if step is None and stt.get("batch_calls", 0) >= 1 and not _NO_DETECT_GRAPH:
             dm.note_scan(dm.rank_dtype if self.ranks_for(dm) else self.spec.wb_dtype, force=True)
+            self.live_check(dm)
             step = stt["step"] = self.capture(dm)
         stt["batch_calls"] = stt.get("batch_calls", 0) + 1
         if step is None:
