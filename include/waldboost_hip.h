@@ -298,8 +298,11 @@ int wb_model_info(const WbModel *model, WbModelInfo *info);
  * ~/.cache/waldboost_amd) and load the model-specialised tile kernel for one kind of byte tile: chn_dtype
  * WB_DTYPE_RANK8, WB_DTYPE_RANK16 or WB_DTYPE_U8.  The model's stage records -- feature offsets, thresholds (model.py:62-67,
  * training.py:24-31), leaf values and theta -- are compile-time constants in it.  wb_cascade_launch uses it from then
- * on for that dtype; results are bit-identical to the generic kernel's.  WB_ERR_UNSUPPORTED for float32 channels and
- * for models on the node-walk kernel; a failed compilation leaves the model on the generic kernel. */
+ * on for that dtype; results are bit-identical to the generic kernel's -- which the call verifies before it returns: the
+ * new kernel and the generic one scan a synthetic pyramid of byte tiles (8,493 windows, six passes; $WB_JIT_SELFTEST) and
+ * must agree on every per-stage alive count and detection record.  WB_ERR_UNSUPPORTED for float32 channels, for models on
+ * the node-walk kernel, and for a model none of whose builds passes that test; a failed compilation or a refused build
+ * leaves the model on the generic kernel. */
 int wb_model_specialize(WbModel *model, int chn_dtype);
 /* ABI 8.  Make wb_cascade_launch ignore (enable = 0) or use again (1) the specialised kernels this model has loaded: with
  * them off the generic kernel scans.  For callers that cross-check a specialised kernel on their own data before they
